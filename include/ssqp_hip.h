@@ -1,0 +1,172 @@
+/*
+ * ssqp_hip.h -- C ABI of libssqp_hip.so, the MI355X (gfx950) backend for the
+ * active-set inner loop of PharosAbad/StatusSwitchingQP.jl.
+ *
+ * The reference has NO FFI layer: its boundary is the Julia method
+ *     solveQP(Q::QP{T}, S, x0; settings)            src/SSQP.jl:237-377
+ * and its wrapper
+ *     solveQP(Q::QP{T}; settings, settingsLP)       src/SSQP.jl:224-234
+ * The entry points below are what a `ccall` from those two methods binds
+ * (INTEGRATION.md shows the Julia side).  Conventions, all taken from the
+ * reference's data model (src/types.jl):
+ *   - matrices are column-major Float64 (Julia Matrix{Float64}):
+ *       V  N x N (symmetric, as stored by the QP constructor, types.jl:243)
+ *       A  M x N,  G  J x N  (M and J may be 0; the pointer is then ignored)
+ *   - vectors q,d,u (N), b (M), g (J); +-Inf encode missing bounds
+ *   - S is Vector{Status} reinterpreted as Int32, length N+J, codes
+ *       IN=0 DN=1 UP=2 OE=3 EO=4  (types.jl:17-23); mutated in place
+ *   - x0 (N) is read only; z (N) receives the solution (SSQP.jl:266)
+ *   - *status is the reference's third return value: iter > 0 on success,
+ *       0 infeasible (Phase-1), -1 numerical/model error, -(maxIter+1) when the
+ *       iteration limit is hit (SSQP.jl:205-209, 272-273)
+ *   - *detail says WHY status == -1 where Julia would have thrown
+ *       (SSQP_DETAIL_*), 0 otherwise
+ * The int return value of every function is an infrastructure code
+ * (SSQP_OK / SSQP_ERR_*), never the solver status.
+ *
+ * The library is re-entrant per ssqp_ctx (one ctx per GPU / per host thread).
+ */
+#ifndef SSQP_HIP_H
+#define SSQP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* infrastructure return codes */
+enum {
+    SSQP_OK = 0,
+    SSQP_ERR_ARG = 1,       /* bad dimension / null pointer */
+    SSQP_ERR_NO_DEVICE = 2, /* no HIP device: the product has no CPU fallback */
+    SSQP_ERR_HIP = 3,       /* a HIP runtime call failed (ssqp_last_error) */
+    SSQP_ERR_ALLOC = 4,
+    SSQP_ERR_UNSUPPORTED = 5 /* e.g. settings.rule != Dantzig */
+};
+
+/* Status codes of S (src/types.jl:17-23) */
+enum { SSQP_IN = 0, SSQP_DN = 1, SSQP_UP = 2, SSQP_OE = 3, SSQP_EO = 4 };
+
+/* detail codes (why status == -1) */
+enum {
+    SSQP_DETAIL_NONE = 0,
+    SSQP_DETAIL_POSDEF_V = 1,  /* cholesky(V[F,F]) not PD    (SSQP.jl:322 throws) */
+    SSQP_DETAIL_POSDEF_C = 2,  /* cholesky(A_E V^-1 A_E') not PD (SSQP.jl:328 throws) */
+    SSQP_DETAIL_SINGULAR_LU = 3, /* Phase-1 basis singular   (Simplex.jl:590 throws) */
+    SSQP_DETAIL_MODEL = 4      /* Q.mc <= 0                  (SSQP.jl:226-228) */
+};
+
+/* Settings{Float64} (src/types.jl:390-408).  `pivot` is read nowhere in the
+ * reference's live code and is not mirrored; `rule`: 0 = :Dantzig (the only
+ * Phase-1 rule implemented; others -> SSQP_ERR_UNSUPPORTED). */
+typedef struct ssqp_settings {
+    int32_t maxIter; /* 7777 */
+    int32_t rule;    /* 0 */
+    double tol;      /* 2^-26 */
+    double tolG;     /* 2^-33 */
+} ssqp_settings;
+
+/* per-problem accounting written by the kernel (for the roofline figures,
+ * SURVEY.md section 8(d)): sums over the iterations the problem ran */
+typedef struct ssqp_stats {
+    int64_t iters;      /* loop passes (== status when status > 0) */
+    int64_t alg_bytes;  /* sum_i 8(K^2+RK+R^2) + 8(M+J)N + 48N + 4(N+J) */
+    int64_t alg_flops;  /* sum_i K^3 + 4K^2W + 2K^2 + 2R^2 + 4RK + ... */
+    int64_t sum_k3;     /* sum_i K^3 */
+    int32_t max_k;      /* largest free set seen */
+    int32_t path;       /* bit0: LDS factor path used, bit1: global-scratch path used */
+} ssqp_stats;
+
+/* one record per loop pass when tracing is requested */
+typedef struct ssqp_trace {
+    int32_t K;    /* free variables */
+    int32_t W;    /* constraint rows kept after the rank filter */
+    int32_t kind; /* 0 K==0 pass (freeK!), 1 blocked step (aStep!), 2 release (KKTchk!), 3 optimal */
+    int32_t id;   /* smallest switched id, 1-based, inequalities N+j; 0 if none */
+} ssqp_trace;
+
+typedef struct ssqp_ctx ssqp_ctx;
+
+/* ---- context ---------------------------------------------------------- */
+/* Creates a context on HIP device `device`.  Fails with SSQP_ERR_NO_DEVICE
+ * when no GPU is present: there is deliberately no CPU fallback. */
+int ssqp_ctx_create(int device, ssqp_ctx **out);
+int ssqp_ctx_destroy(ssqp_ctx *ctx);
+const char *ssqp_last_error(const ssqp_ctx *ctx);
+/* library/version string, safe without a GPU */
+const char *ssqp_version(void);
+/* Settings{Float64}() defaults (types.jl:401-408) */
+void ssqp_default_settings(ssqp_settings *s);
+
+/* ---- hot path: replaces solveQP(Q, S, x0; settings), SSQP.jl:237 -------- */
+/* Host buffers (what the Julia ccall passes).  Copies the problem to the
+ * device, runs the in-kernel active-set loop, copies z,S back. */
+int ssqp_solve_f64(ssqp_ctx *ctx, int N, int M, int J, const double *V, const double *A,
+                   const double *G, const double *q, const double *b, const double *g,
+                   const double *d, const double *u, int32_t *S, const double *x0, double *z,
+                   const ssqp_settings *settings, int64_t *status, int32_t *detail);
+
+/* ---- replaces solveQP(Q; settings, settingsLP), SSQP.jl:224 ------------- */
+/* mc = Q.mc (types.jl:240-284).  Phase-1 (initQP, SSQP.jl:461-560) runs on
+ * the host, the loop on the GPU. */
+int ssqp_solve_full_f64(ssqp_ctx *ctx, int N, int M, int J, const double *V, const double *A,
+                        const double *G, const double *q, const double *b, const double *g,
+                        const double *d, const double *u, int mc, int32_t *S, double *z,
+                        const ssqp_settings *settings, const ssqp_settings *settingsLP,
+                        int64_t *status, int32_t *detail);
+
+/* ---- batches of independent QPs of equal shape --------------------------- */
+/* Host buffers, problems stored back to back (problem p at offset p*len). */
+int ssqp_solve_batch_f64(ssqp_ctx *ctx, int nprob, int N, int M, int J, const double *V,
+                         const double *A, const double *G, const double *q, const double *b,
+                         const double *g, const double *d, const double *u, int32_t *S,
+                         const double *x0, double *z, const ssqp_settings *settings,
+                         int64_t *status, int32_t *detail, ssqp_stats *stats);
+
+/* Device-resident buffers (all pointers are device pointers on ctx's GPU;
+ * stats/trace may be NULL).  Asynchronous on `stream` (a hipStream_t passed
+ * as void*; NULL = the context's own stream); ssqp_sync waits for it.
+ * trace holds ntrace records per problem. */
+int ssqp_solve_batch_dev_f64(ssqp_ctx *ctx, int nprob, int N, int M, int J, const double *dV,
+                             const double *dA, const double *dG, const double *dq,
+                             const double *db, const double *dg, const double *dd,
+                             const double *du, int32_t *dS, const double *dx0, double *dz,
+                             const ssqp_settings *settings, int64_t *dstatus, int32_t *ddetail,
+                             ssqp_stats *dstats, ssqp_trace *dtrace, int ntrace, void *stream);
+int ssqp_sync(ssqp_ctx *ctx, void *stream);
+/* duration in ms of the solve kernel of the most recent ssqp_solve_batch_dev_f64
+ * on this ctx, from HIP events recorded on the launch stream (call after sync) */
+int ssqp_last_kernel_ms(ssqp_ctx *ctx, float *ms);
+
+/* ---- Phase-1: replaces initQP(Q, settingsLP), SSQP.jl:461-560 (host C++) -- */
+/* *status: 1 feasible, 0 infeasible, -1 basis singular. */
+int ssqp_phase1_f64(int N, int M, int J, const double *A, const double *G, const double *b,
+                    const double *g, const double *d, const double *u,
+                    const ssqp_settings *settingsLP, double *x0, int32_t *S, int32_t *status);
+int ssqp_phase1_batch_f64(int nprob, int N, int M, int J, const double *A, const double *G,
+                          const double *b, const double *g, const double *d, const double *u,
+                          const ssqp_settings *settingsLP, double *x0, int32_t *S,
+                          int32_t *status, int nthreads);
+
+/* ---- deterministic synthetic problems ---------- */
+/* V = X'X/T + delta*I, X (T x N) iid U(-1/2,1/2) from a SplitMix64 counter
+ * stream; A row 0 = ones (budget), rows 1.. = random 0/1 group sums with
+ * b = A*(1/N); G iid U(0,1), g_j = gscale*mean(G[j,:]); d = 0, u = ub
+ * (+Inf when ub <= 0); q = -qscale*mu, mu iid U(0,0.2).  Sequential f64
+ * accumulation without FMA contraction: every caller gets identical bits. */
+typedef struct ssqp_gen_cfg {
+    int32_t N, M, J, T;
+    double delta, ub, gscale, qscale;
+} ssqp_gen_cfg;
+int ssqp_generate_problem(const ssqp_gen_cfg *cfg, uint64_t seed, double *V, double *A,
+                          double *G, double *q, double *b, double *g, double *d, double *u);
+int ssqp_generate_batch(const ssqp_gen_cfg *cfg, uint64_t seed0, int nprob, double *V,
+                        double *A, double *G, double *q, double *b, double *g, double *d,
+                        double *u, int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSQP_HIP_H */

@@ -1,0 +1,274 @@
+// ssqp_api.hip -- the C ABI of libssqp_hip.so (include/ssqp_hip.h): context,
+// workspaces, launches.  The solver itself is ssqp_kernels.hip; there is no
+// CPU fallback anywhere in this library: without a HIP device
+// ssqp_ctx_create fails with SSQP_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ssqp_hip.h"
+#include "ssqp_internal.h"
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct ssqp_ctx {
+    int device = 0;
+    int numCU = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::string err;
+    // grow-only device workspaces
+    DevBuf Ct, rhs, queue, gscratch;
+    // staging buffers of the host-pointer entry points
+    DevBuf hV, hA, hG, hq, hb, hg, hd, hu, hS, hx0, hz, hstatus, hdetail, hstats;
+};
+
+namespace {
+
+bool hip_ok(ssqp_ctx *c, hipError_t e, const char *what) {
+    if (e == hipSuccess) return true;
+    if (c) c->err = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+
+bool ensure(ssqp_ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 8;
+    if (b.bytes >= bytes) return true;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+    if (!hip_ok(c, hipMalloc(&b.p, bytes), "hipMalloc")) return false;
+    b.bytes = bytes;
+    return true;
+}
+
+void release(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+int check_dims(ssqp_ctx *c, int nprob, int N, int M, int J) {
+    if (!c) return SSQP_ERR_ARG;
+    if (nprob < 0 || N <= 0 || M < 0 || J < 0) {
+        c->err = "bad dimensions";
+        return SSQP_ERR_ARG;
+    }
+    if (N > ssqp::MAXN || N + J + 2 > 32767 || M + J + 2 > 32767) {
+        c->err = "N above the in-kernel limit (2048)";
+        return SSQP_ERR_UNSUPPORTED;
+    }
+    if (ssqp::lds_fixed_bytes(N, M, J) + 1024 > ssqp::LDS_BYTES) {
+        c->err = "N/M/J vectors do not fit in LDS";
+        return SSQP_ERR_UNSUPPORTED;
+    }
+    return SSQP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssqp_ctx_create(int device, ssqp_ctx **out) {
+    if (!out) return SSQP_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return SSQP_ERR_NO_DEVICE;
+    ssqp_ctx *c = new (std::nothrow) ssqp_ctx();
+    if (!c) return SSQP_ERR_ALLOC;
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        delete c;
+        return SSQP_ERR_NO_DEVICE;
+    }
+    c->numCU = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return SSQP_ERR_HIP;
+    }
+    *out = c;
+    return SSQP_OK;
+}
+
+int ssqp_ctx_destroy(ssqp_ctx *c) {
+    if (!c) return SSQP_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->Ct, &c->rhs, &c->queue, &c->gscratch, &c->hV, &c->hA, &c->hG, &c->hq, &c->hb, &c->hg,
+                      &c->hd, &c->hu, &c->hS, &c->hx0, &c->hz, &c->hstatus, &c->hdetail, &c->hstats})
+        release(*b);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SSQP_OK;
+}
+
+const char *ssqp_last_error(const ssqp_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int ssqp_sync(ssqp_ctx *c, void *stream) {
+    if (!c) return SSQP_ERR_ARG;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return hip_ok(c, hipStreamSynchronize(s), "hipStreamSynchronize") ? SSQP_OK : SSQP_ERR_HIP;
+}
+
+int ssqp_last_kernel_ms(ssqp_ctx *c, float *ms) {
+    if (!c || !ms) return SSQP_ERR_ARG;
+    if (!c->timed) {
+        c->err = "no solve has been launched on this context";
+        return SSQP_ERR_ARG;
+    }
+    if (!hip_ok(c, hipEventSynchronize(c->ev1), "hipEventSynchronize")) return SSQP_ERR_HIP;
+    return hip_ok(c, hipEventElapsedTime(ms, c->ev0, c->ev1), "hipEventElapsedTime") ? SSQP_OK : SSQP_ERR_HIP;
+}
+
+int ssqp_solve_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const double *dV, const double *dA,
+                             const double *dG, const double *dq, const double *db, const double *dg,
+                             const double *dd, const double *du, int32_t *dS, const double *dx0, double *dz,
+                             const ssqp_settings *settings, int64_t *dstatus, int32_t *ddetail,
+                             ssqp_stats *dstats, ssqp_trace *dtrace, int ntrace, void *stream) {
+    int rc = check_dims(c, nprob, N, M, J);
+    if (rc != SSQP_OK) return rc;
+    if (!dV || !dq || !dd || !du || !dS || !dx0 || !dz || !dstatus || (M > 0 && (!dA || !db)) ||
+        (J > 0 && (!dG || !dg))) {
+        c->err = "null pointer";
+        return SSQP_ERR_ARG;
+    }
+    if (nprob == 0) return SSQP_OK;
+    ssqp_settings def;
+    ssqp_default_settings(&def);
+    const ssqp_settings *st = settings ? settings : &def;
+    if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return SSQP_ERR_HIP;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+
+    const int MJ = M + J;
+    int grid = nprob < c->numCU ? nprob : c->numCU;
+    if (grid < 1) grid = 1;
+    const size_t gstride = ssqp::global_arena_doubles(N, M, J);
+    if (!ensure(c, c->Ct, (size_t)nprob * MJ * N * 8) || !ensure(c, c->rhs, (size_t)nprob * MJ * 8) ||
+        !ensure(c, c->queue, 64) || !ensure(c, c->gscratch, (size_t)grid * gstride * 8))
+        return SSQP_ERR_ALLOC;
+
+    ssqp::SolveParams P;
+    P.nprob = nprob; P.N = N; P.M = M; P.J = J; P.MJ = MJ;
+    P.V = dV;
+    P.Ct = (const double *)c->Ct.p;
+    P.rhs = (const double *)c->rhs.p;
+    P.q = dq; P.d = dd; P.u = du; P.x0 = dx0;
+    P.S = dS; P.z = dz; P.status = dstatus; P.detail = ddetail; P.stats = dstats;
+    P.trace = (ntrace > 0) ? dtrace : nullptr;
+    P.ntrace = (dtrace && ntrace > 0) ? ntrace : 0;
+    P.maxIter = st->maxIter; P.tol = st->tol; P.tolG = st->tolG;
+    P.queue = (unsigned int *)c->queue.p;
+    P.gscratch = (double *)c->gscratch.p;
+    P.gscratchStride = gstride;
+    const int fixed = ssqp::lds_fixed_bytes(N, M, J);
+    P.arenaCap = ((ssqp::LDS_BYTES - fixed - 64) / 16) * 2;
+    const ssqp::LdsLayout lay = ssqp::lds_layout(N, M, J, P.arenaCap);
+    if (lay.total_bytes > ssqp::LDS_BYTES) {
+        c->err = "internal: LDS layout overflow";
+        return SSQP_ERR_UNSUPPORTED;
+    }
+
+    if (!hip_ok(c, hipMemsetAsync(c->queue.p, 0, 64, s), "hipMemsetAsync")) return SSQP_ERR_HIP;
+    ssqp::launch_prep(nprob, N, M, J, dA, dG, db, dg, (double *)c->Ct.p, (double *)c->rhs.p, s);
+    if (!hip_ok(c, hipGetLastError(), "prep launch")) return SSQP_ERR_HIP;
+    if (!hip_ok(c, hipEventRecord(c->ev0, s), "hipEventRecord")) return SSQP_ERR_HIP;
+    if (!hip_ok(c, ssqp::launch_solve(P, grid, (size_t)lay.total_bytes, s), "solve launch")) return SSQP_ERR_HIP;
+    if (!hip_ok(c, hipEventRecord(c->ev1, s), "hipEventRecord")) return SSQP_ERR_HIP;
+    c->timed = true;
+    return SSQP_OK;
+}
+
+int ssqp_solve_batch_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const double *V, const double *A,
+                         const double *G, const double *q, const double *b, const double *g, const double *d,
+                         const double *u, int32_t *S, const double *x0, double *z, const ssqp_settings *settings,
+                         int64_t *status, int32_t *detail, ssqp_stats *stats) {
+    int rc = check_dims(c, nprob, N, M, J);
+    if (rc != SSQP_OK) return rc;
+    if (!V || !q || !d || !u || !S || !x0 || !z || !status || (M > 0 && (!A || !b)) || (J > 0 && (!G || !g))) {
+        c->err = "null pointer";
+        return SSQP_ERR_ARG;
+    }
+    if (nprob == 0) return SSQP_OK;
+    if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return SSQP_ERR_HIP;
+    const size_t P = nprob, n = N, m = M, j = J;
+    struct Up { DevBuf *buf; const void *src; size_t bytes; };
+    const Up ups[] = {{&c->hV, V, P * n * n * 8}, {&c->hA, A, P * m * n * 8}, {&c->hG, G, P * j * n * 8},
+                      {&c->hq, q, P * n * 8},     {&c->hb, b, P * m * 8},     {&c->hg, g, P * j * 8},
+                      {&c->hd, d, P * n * 8},     {&c->hu, u, P * n * 8},     {&c->hS, S, P * (n + j) * 4},
+                      {&c->hx0, x0, P * n * 8}};
+    for (const Up &up : ups) {
+        if (!ensure(c, *up.buf, up.bytes)) return SSQP_ERR_ALLOC;
+        if (up.bytes && up.src &&
+            !hip_ok(c, hipMemcpyAsync(up.buf->p, up.src, up.bytes, hipMemcpyHostToDevice, c->stream), "H2D"))
+            return SSQP_ERR_HIP;
+    }
+    if (!ensure(c, c->hz, P * n * 8) || !ensure(c, c->hstatus, P * 8) || !ensure(c, c->hdetail, P * 4) ||
+        !ensure(c, c->hstats, P * sizeof(ssqp_stats)))
+        return SSQP_ERR_ALLOC;
+    rc = ssqp_solve_batch_dev_f64(c, nprob, N, M, J, (const double *)c->hV.p, (const double *)c->hA.p,
+                                  (const double *)c->hG.p, (const double *)c->hq.p, (const double *)c->hb.p,
+                                  (const double *)c->hg.p, (const double *)c->hd.p, (const double *)c->hu.p,
+                                  (int32_t *)c->hS.p, (const double *)c->hx0.p, (double *)c->hz.p, settings,
+                                  (int64_t *)c->hstatus.p, (int32_t *)c->hdetail.p, (ssqp_stats *)c->hstats.p,
+                                  nullptr, 0, c->stream);
+    if (rc != SSQP_OK) return rc;
+    if (!hip_ok(c, hipMemcpyAsync(z, c->hz.p, P * n * 8, hipMemcpyDeviceToHost, c->stream), "D2H") ||
+        !hip_ok(c, hipMemcpyAsync(S, c->hS.p, P * (n + j) * 4, hipMemcpyDeviceToHost, c->stream), "D2H") ||
+        !hip_ok(c, hipMemcpyAsync(status, c->hstatus.p, P * 8, hipMemcpyDeviceToHost, c->stream), "D2H"))
+        return SSQP_ERR_HIP;
+    if (detail && !hip_ok(c, hipMemcpyAsync(detail, c->hdetail.p, P * 4, hipMemcpyDeviceToHost, c->stream), "D2H"))
+        return SSQP_ERR_HIP;
+    if (stats && !hip_ok(c, hipMemcpyAsync(stats, c->hstats.p, P * sizeof(ssqp_stats), hipMemcpyDeviceToHost,
+                                           c->stream), "D2H"))
+        return SSQP_ERR_HIP;
+    if (!hip_ok(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return SSQP_ERR_HIP;
+    return SSQP_OK;
+}
+
+int ssqp_solve_f64(ssqp_ctx *c, int N, int M, int J, const double *V, const double *A, const double *G,
+                   const double *q, const double *b, const double *g, const double *d, const double *u, int32_t *S,
+                   const double *x0, double *z, const ssqp_settings *settings, int64_t *status, int32_t *detail) {
+    return ssqp_solve_batch_f64(c, 1, N, M, J, V, A, G, q, b, g, d, u, S, x0, z, settings, status, detail, nullptr);
+}
+
+int ssqp_solve_full_f64(ssqp_ctx *c, int N, int M, int J, const double *V, const double *A, const double *G,
+                        const double *q, const double *b, const double *g, const double *d, const double *u, int mc,
+                        int32_t *S, double *z, const ssqp_settings *settings, const ssqp_settings *settingsLP,
+                        int64_t *status, int32_t *detail) {
+    if (!c || !S || !z || !status || N <= 0) return SSQP_ERR_ARG;
+    if (detail) *detail = SSQP_DETAIL_NONE;
+    if (mc <= 0) {  // SSQP.jl:226-228
+        for (int k = 0; k < N; ++k) {
+            z[k] = 0.0;
+            S[k] = SSQP_DN;
+        }
+        *status = -1;
+        if (detail) *detail = SSQP_DETAIL_MODEL;
+        return SSQP_OK;
+    }
+    std::vector<double> x0(N);
+    int32_t st1 = 0;
+    int rc = ssqp_phase1_f64(N, M, J, A, G, b, g, d, u, settingsLP ? settingsLP : settings, x0.data(), S, &st1);
+    if (rc != SSQP_OK) return rc;
+    if (st1 <= 0) {  // SSQP.jl:230-232
+        std::memcpy(z, x0.data(), sizeof(double) * (size_t)N);
+        *status = st1;
+        if (st1 < 0 && detail) *detail = SSQP_DETAIL_SINGULAR_LU;
+        return SSQP_OK;
+    }
+    return ssqp_solve_f64(c, N, M, J, V, A, G, q, b, g, d, u, S, x0.data(), z, settings, status, detail);
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+// ssqp_internal.h -- shared between the kernels (ssqp_kernels.hip) and the
+// C-ABI host layer (ssqp_api.hip).  Not part of the public interface.
+#ifndef SSQP_INTERNAL_H
+#define SSQP_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ssqp_hip.h"
+
+namespace ssqp {
+
+constexpr int NT = 512;          // threads per workgroup (8 wavefronts of 64)
+constexpr int NW = NT / 64;      // wavefronts per workgroup
+constexpr int MAXPT = 4;         // per-thread slots over the free list
+constexpr int MAXN = NT * MAXPT; // largest N the in-kernel loop accepts (2048)
+constexpr int LDS_BYTES = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup may use all
+
+struct SolveParams {
+    int nprob, N, M, J, MJ;
+    const double *V;    // nprob x (N x N) column-major, symmetric
+    const double *Ct;   // nprob x (MJ x N): row r of [A;G] contiguous
+    const double *rhs;  // nprob x MJ: [b; g]
+    const double *q, *d, *u, *x0;
+    int32_t *S;
+    double *z;
+    int64_t *status;
+    int32_t *detail;
+    ssqp_stats *stats;
+    ssqp_trace *trace;
+    int ntrace;
+    int maxIter;
+    double tol, tolG;
+    unsigned int *queue;     // work counter, zeroed before the launch
+    double *gscratch;        // per-workgroup global arena (used when the LDS arena is too small)
+    size_t gscratchStride;   // doubles per workgroup
+    int arenaCap;            // doubles in the LDS arena
+};
+
+// Offsets of the LDS carve-up.  Double-typed regions first (offsets in
+// doubles), then the integer regions (offsets in bytes).
+struct LdsLayout {
+    int z, zm, gam, arena, bE, aL, tv, dcol, lin, red;  // in doubles
+    int S_bytes, ired_bytes, pos_bytes, idx_bytes, perm_bytes, rowsE_bytes, ra_bytes, iO_bytes;
+    int total_bytes;
+};
+
+__host__ __device__ inline int align_up(int x, int a) { return (x + a - 1) / a * a; }
+
+// bytes of everything except the arena
+__host__ __device__ inline int lds_fixed_bytes(int N, int M, int J) {
+    const int MJ1 = align_up(M + J + 1, 2);
+    int dbl = 3 * align_up(N, 2) + 5 * MJ1 + 2 * NW;
+    int bytes = dbl * 8;
+    bytes += align_up(4 * (N + J), 8);           // S
+    bytes += align_up(4 * (2 * NW + 8), 8);      // ired
+    bytes += 3 * align_up(2 * (N + 2), 8);       // pos, idx, perm
+    bytes += 3 * align_up(2 * (M + J + 2), 8);   // rowsE, ra, iO
+    return bytes;
+}
+
+__host__ __device__ inline LdsLayout lds_layout(int N, int M, int J, int arenaCap) {
+    LdsLayout l;
+    const int Np = align_up(N, 2), MJ1 = align_up(M + J + 1, 2);
+    int o = 0;
+    l.z = o; o += Np;
+    l.zm = o; o += Np;
+    l.gam = o; o += Np;
+    l.bE = o; o += MJ1;
+    l.aL = o; o += MJ1;
+    l.tv = o; o += MJ1;
+    l.dcol = o; o += MJ1;
+    l.lin = o; o += MJ1;
+    l.red = o; o += 2 * NW;
+    l.arena = o; o += align_up(arenaCap, 2);
+    int b = o * 8;
+    l.S_bytes = b; b += align_up(4 * (N + J), 8);
+    l.ired_bytes = b; b += align_up(4 * (2 * NW + 8), 8);
+    l.pos_bytes = b; b += align_up(2 * (N + 2), 8);
+    l.idx_bytes = b; b += align_up(2 * (N + 2), 8);
+    l.perm_bytes = b; b += align_up(2 * (N + 2), 8);
+    l.rowsE_bytes = b; b += align_up(2 * (M + J + 2), 8);
+    l.ra_bytes = b; b += align_up(2 * (M + J + 2), 8);
+    l.iO_bytes = b; b += align_up(2 * (M + J + 2), 8);
+    l.total_bytes = b;
+    return l;
+}
+
+// doubles one workgroup may need in the global arena (K = N, W0 = M+J)
+inline size_t global_arena_doubles(int N, int M, int J) {
+    const size_t K = N, W0 = M + J, R = K + W0 + 1;
+    const size_t packed = K * R - K * (K - 1) / 2;
+    const size_t x = W0 * (K + 1) + W0;
+    const size_t f = packed + K + W0 * W0 + 2 * K + 64;
+    return (x > f ? x : f) + 64;
+}
+
+void launch_prep(int nprob, int N, int M, int J, const double *A, const double *G, const double *b,
+                 const double *g, double *Ct, double *rhs, hipStream_t stream);
+hipError_t launch_solve(const SolveParams &P, int grid, size_t ldsBytes, hipStream_t stream);
+
+}  // namespace ssqp
+#endif

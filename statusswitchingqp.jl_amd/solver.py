@@ -1,0 +1,248 @@
+"""solveQP and batch drivers: the reference's entry points over the C ABI.
+
+    solveQP(Q; settings, settingsLP)        src/SSQP.jl:224-234
+    solveQP(Q, S, x0; settings)             src/SSQP.jl:237-377   <- the GPU hot path
+
+Every solve goes through libssqp_hip.so; nothing here computes a solution on
+the CPU.  PyTorch is used only to hold device memory / streams for the
+device-resident batch entry point.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+from .types import QP, Settings, Status
+
+_default_ctx = None
+
+
+def _csettings(s):
+    s = s or Settings()
+    if s.rule != "Dantzig":
+        raise _capi.SSQPError("only rule=:Dantzig is implemented for Phase-1 (got :%s)" % s.rule)
+    return _capi.CSettings(s.maxIter, 0, s.tol, s.tolG)
+
+
+class Context:
+    """One per GPU (ssqp_ctx).  Raises NoDeviceError when no GPU is present."""
+
+    def __init__(self, device=None):
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = device
+        self._h = C.c_void_p()
+        _capi.check(_capi.lib().ssqp_ctx_create(device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            _capi.lib().ssqp_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        _capi.check(_capi.lib().ssqp_last_kernel_ms(self._h, C.byref(ms)), self._h)
+        return ms.value
+
+    def sync(self, stream=None):
+        _capi.check(_capi.lib().ssqp_sync(self._h, stream), self._h)
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def solveQP(Q, S=None, x0=None, settings=None, settingsLP=None, ctx=None, return_detail=False):
+    """z, S, status = solveQP(Q)            Phase-1 on the host, loop on the GPU
+       z, S, status = solveQP(Q, S, x0)     warm start: the hot path only; S is mutated in place
+
+    status > 0: iterations used; 0 infeasible; -1 numerical/model error; -(maxIter+1) iteration limit.
+    """
+    if not isinstance(Q, QP):
+        raise TypeError("solveQP expects a QP")
+    ctx = ctx or default_context()
+    lib = _capi.lib()
+    cs = _csettings(settings)
+    N, M, J = Q.N, Q.M, Q.J
+    z = np.zeros(N)
+    status = C.c_int64(0)
+    detail = C.c_int32(0)
+    if (S is None) != (x0 is None):
+        raise TypeError("solveQP(Q, S, x0): S and x0 go together")
+    if S is None:
+        csl = _csettings(settingsLP or settings)
+        if Q.mc <= 0:  # the reference returns fill(DN, N) here (SSQP.jl:227)
+            Sout = np.full(N, int(Status.DN), dtype=np.int32)
+        else:
+            Sout = np.zeros(N + J, dtype=np.int32)
+        rc = lib.ssqp_solve_full_f64(ctx.handle, N, M, J, _p(Q.V), _p(Q.A), _p(Q.G), _p(Q.q), _p(Q.b), _p(Q.g),
+                                     _p(Q.d), _p(Q.u), Q.mc, _p(Sout), _p(z), C.byref(cs), C.byref(csl),
+                                     C.byref(status), C.byref(detail))
+        _capi.check(rc, ctx.handle)
+    else:
+        if not (isinstance(S, np.ndarray) and S.dtype == np.int32 and S.flags.c_contiguous and S.size == N + J):
+            raise TypeError("S must be a contiguous int32 array of length N+J (Vector{Status})")
+        Sout = S
+        x0 = _f64(x0)
+        rc = lib.ssqp_solve_f64(ctx.handle, N, M, J, _p(Q.V), _p(Q.A), _p(Q.G), _p(Q.q), _p(Q.b), _p(Q.g), _p(Q.d),
+                                _p(Q.u), _p(Sout), _p(x0), _p(z), C.byref(cs), C.byref(status), C.byref(detail))
+        _capi.check(rc, ctx.handle)
+    if return_detail:
+        return z, Sout, int(status.value), int(detail.value)
+    return z, Sout, int(status.value)
+
+
+# ----------------------------------------------------------------------------
+# batches of equal-shape QPs.  Arrays are "column-major blocks": V[p] is the
+# N x N column-major image (symmetric, so V[p] == V[p].T), A[p] has shape (N, M)
+# with A[p][j, r] = A_p[r, j], G[p] likewise (N, J).
+# ----------------------------------------------------------------------------
+class GenConfig:
+    """Synthetic problem family; see ssqp_generate_problem."""
+
+    def __init__(self, N, M=1, J=0, T=None, delta=1e-3, ub=0.0, gscale=1.2, qscale=0.0):
+        self.N, self.M, self.J = int(N), int(M), int(J)
+        self.T = int(T if T is not None else 2 * N)
+        self.delta, self.ub, self.gscale, self.qscale = float(delta), float(ub), float(gscale), float(qscale)
+
+    def c(self):
+        return _capi.CGenCfg(self.N, self.M, self.J, self.T, self.delta, self.ub, self.gscale, self.qscale)
+
+
+BASE_SEED = 20261003
+
+CONFIGS = {
+    "cfg1": GenConfig(50, 1, 0, 100, 1e-3, 0.0, 1.2, 0.0),
+    "cfg2": GenConfig(512, 1, 10, 1024, 1e-3, 3 / 64, 1.2, 0.1),
+    "cfg3": GenConfig(256, 1, 0, 512, 1e-3, 3 / 32, 1.2, 0.0),
+    "cfg4": GenConfig(512, 1, 10, 1024, 1e-3, 3 / 64, 1.2, 0.1),
+    "cfg4_j0": GenConfig(512, 1, 0, 1024, 1e-3, 3 / 64, 1.2, 0.1),
+    "cfg5": GenConfig(2048, 8, 64, 1024, 0.0, 3 / 128, 1.2, 0.1),
+}
+
+
+def generate_batch(cfg, nprob, seed0=BASE_SEED, nthreads=0):
+    """dict of numpy arrays V,A,G,q,b,g,d,u for problems seed0 .. seed0+nprob-1."""
+    N, M, J = cfg.N, cfg.M, cfg.J
+    out = dict(V=np.zeros((nprob, N, N)), A=np.zeros((nprob, N, M)), G=np.zeros((nprob, N, J)),
+               q=np.zeros((nprob, N)), b=np.zeros((nprob, M)), g=np.zeros((nprob, J)), d=np.zeros((nprob, N)),
+               u=np.zeros((nprob, N)))
+    cc = cfg.c()
+    rc = _capi.lib().ssqp_generate_batch(C.byref(cc), seed0, nprob, *[_p(out[k]) for k in "VAGqbgdu"], nthreads)
+    _capi.check(rc)
+    return out
+
+
+def phase1_batch(prob, settingsLP=None, nthreads=0):
+    """initQP for every problem of a batch (host C++): x0 (P,N), S (P,N+J) int32, status (P,)."""
+    P, N = prob["q"].shape
+    M, J = prob["b"].shape[1], prob["g"].shape[1]
+    x0 = np.zeros((P, N))
+    S = np.zeros((P, N + J), dtype=np.int32)
+    st = np.zeros(P, dtype=np.int32)
+    cs = _csettings(settingsLP)
+    rc = _capi.lib().ssqp_phase1_batch_f64(P, N, M, J, *[_p(_f64(prob[k])) for k in "AGbgdu"], C.byref(cs), _p(x0),
+                                           _p(S), _p(st), nthreads)
+    _capi.check(rc)
+    return x0, S, st
+
+
+def solveQP_batch(prob, S, x0, settings=None, ctx=None, want_stats=False):
+    """Hot path on a batch held in host memory.  Returns z (P,N), S (P,N+J) copy, status (P,), detail (P,)[, stats]."""
+    ctx = ctx or default_context()
+    P, N = prob["q"].shape
+    M, J = prob["b"].shape[1], prob["g"].shape[1]
+    arrs = [_f64(prob[k]) for k in "VAGqbgdu"]
+    S = np.ascontiguousarray(S, dtype=np.int32).copy()
+    x0 = _f64(x0)
+    z = np.zeros((P, N))
+    status = np.zeros(P, dtype=np.int64)
+    detail = np.zeros(P, dtype=np.int32)
+    stats = (_capi.CStats * P)()
+    cs = _csettings(settings)
+    rc = _capi.lib().ssqp_solve_batch_f64(ctx.handle, P, N, M, J, *[_p(a) for a in arrs], _p(S), _p(x0), _p(z),
+                                          C.byref(cs), _p(status), _p(detail), C.cast(stats, C.c_void_p))
+    _capi.check(rc, ctx.handle)
+    if want_stats:
+        return z, S, status, detail, stats_to_numpy(stats)
+    return z, S, status, detail
+
+
+STATS_DTYPE = np.dtype([("iters", "<i8"), ("alg_bytes", "<i8"), ("alg_flops", "<i8"), ("sum_k3", "<i8"),
+                        ("max_k", "<i4"), ("path", "<i4")])
+TRACE_DTYPE = np.dtype([("K", "<i4"), ("W", "<i4"), ("kind", "<i4"), ("id", "<i4")])
+
+
+def stats_to_numpy(stats):
+    return np.frombuffer(bytes(stats), dtype=STATS_DTYPE).copy()
+
+
+class DeviceBatch:
+    """A batch resident in HBM (torch tensors hold the memory) + the launch of the in-kernel loop."""
+
+    def __init__(self, prob, S0, x0, ctx=None, ntrace=0, device=None):
+        import torch
+        self.torch = torch
+        self.ctx = ctx or default_context()
+        dev = torch.device("cuda", self.ctx.device if device is None else device)
+        self.P, self.N = prob["q"].shape
+        self.M, self.J = prob["b"].shape[1], prob["g"].shape[1]
+        self.t = {k: torch.from_numpy(_f64(prob[k])).to(dev) for k in "VAGqbgdu"}
+        self.S0 = torch.from_numpy(np.ascontiguousarray(S0, dtype=np.int32)).to(dev)
+        self.x0 = torch.from_numpy(_f64(x0)).to(dev)
+        self.S = torch.empty_like(self.S0)
+        self.z = torch.zeros((self.P, self.N), dtype=torch.float64, device=dev)
+        self.status = torch.zeros(self.P, dtype=torch.int64, device=dev)
+        self.detail = torch.zeros(self.P, dtype=torch.int32, device=dev)
+        self.stats = torch.zeros((self.P, STATS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        self.ntrace = int(ntrace)
+        self.trace = torch.zeros((self.P, max(self.ntrace, 1), 4), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+
+    @staticmethod
+    def _ptr(t):
+        return C.c_void_p(t.data_ptr()) if t.numel() else None
+
+    def solve(self, settings=None, stream=None):
+        """One pass of the hot path over the batch (asynchronous on `stream`, default torch's current stream)."""
+        torch = self.torch
+        cs = _csettings(settings)
+        self.S.copy_(self.S0)  # S is in/out
+        if stream is None:
+            stream = torch.cuda.current_stream(self.S.device).cuda_stream
+        t = self.t
+        rc = _capi.lib().ssqp_solve_batch_dev_f64(
+            self.ctx.handle, self.P, self.N, self.M, self.J, *[self._ptr(t[k]) for k in "VAGqbgdu"],
+            self._ptr(self.S), self._ptr(self.x0), self._ptr(self.z), C.byref(cs), self._ptr(self.status),
+            self._ptr(self.detail), self._ptr(self.stats), self._ptr(self.trace) if self.ntrace else None,
+            self.ntrace, C.c_void_p(stream))
+        _capi.check(rc, self.ctx.handle)
+
+    def results(self):
+        self.torch.cuda.synchronize(self.S.device)
+        stats = np.frombuffer(self.stats.cpu().numpy().tobytes(), dtype=STATS_DTYPE).copy()
+        trace = self.trace.cpu().numpy() if self.ntrace else None
+        return dict(z=self.z.cpu().numpy(), S=self.S.cpu().numpy(), status=self.status.cpu().numpy(),
+                    detail=self.detail.cpu().numpy(), stats=stats, trace=trace)
