@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- QPs/sec of the in-kernel active-set loop on batched N=512 dense portfolio QPs.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (solveQP(Q,S,x0), SSQP.jl:237-377) over one batch of
+synthetic QPs already resident in HBM: BASELINE.json configs[3] ("8192 independent N=512 QPs
+sharded across 8 GPUs") = 1024 QPs per GPU, cfg2-style problems (M=1, J=10, box bounds).
+Weak scaling: every rank owns 1024 problems; the only collective is the final RCCL all-gather of
+(z, S, status), inside the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nprob", type=int, default=1024, help="QPs per GPU")
+    ap.add_argument("--config", default="cfg4", help="problem family (statusswitchingqp.jl_amd CONFIGS)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"),
+                    help="per-launch HBM bytes from a separate rocprofv3 --pmc pass, if present")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    cfg = pkg.CONFIGS[args.config]
+    ncpu = len(os.sched_getaffinity(0))
+    gen_threads = max(1, ncpu // max(1, min(world, 8)))
+    t0 = time.time()
+    prob = pkg.generate_batch(cfg, args.nprob, pkg.BASE_SEED + rank * args.nprob, nthreads=gen_threads)
+    x0, S0, st1 = pkg.phase1_batch(prob, nthreads=gen_threads)
+    assert (st1 == 1).all(), "Phase-1 failed on a synthetic problem"
+    t_setup = time.time() - t0
+
+    ctx = pkg.Context(local)
+    batch = pkg.DeviceBatch(prob, S0, x0, ctx=ctx, device=local)
+    P, N, J = batch.P, batch.N, batch.J
+    stream = torch.cuda.current_stream(dev)
+
+    if world > 1:
+        gz = torch.empty((world * P, N), dtype=torch.float64, device=dev)
+        gS = torch.empty((world * P, N + J), dtype=torch.int32, device=dev)
+        gst = torch.empty((world * P,), dtype=torch.int64, device=dev)
+
+    def step():
+        batch.solve()                       # in-kernel active-set loop, asynchronous on torch's stream
+        if world > 1:                       # final gather of the sharded batch (RCCL over xGMI)
+            dist.all_gather_into_tensor(gz, batch.z)
+            dist.all_gather_into_tensor(gS, batch.S)
+            dist.all_gather_into_tensor(gst, batch.status)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t_start
+    # kernel duration of the LAST timed step: HIP events the library records on the launch stream
+    last_kernel_ms = ctx.last_kernel_ms()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    res = batch.results()
+    ok = bool((res["status"] > 0).all())
+    stats = res["stats"]
+    alg_bytes = int(stats["alg_bytes"].sum())
+    iters = res["status"].astype(np.int64)
+
+    # a few more launches, each timed by its own HIP events, for the roofline figure
+    kms = []
+    for _ in range(3):
+        batch.solve()
+        torch.cuda.synchronize(dev)
+        kms.append(ctx.last_kernel_ms())
+    k_ms = float(np.mean(kms + [last_kernel_ms]))
+
+    traffic = None
+    if os.path.exists(args.traffic_json):
+        try:
+            with open(args.traffic_json) as f:
+                tj = json.load(f)
+            if tj.get("config") == args.config and tj.get("nprob") == args.nprob:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = None
+    if rank == 0:
+        qps = world * P * args.steps / elapsed
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "QPs/sec (batched N=512 dense portfolio QP, solveQP(Q,S,x0) to KKT)",
+            "value": qps, "unit": "QPs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %d QPs/GPU, N=%d M=%d J=%d, V=X'X/T+1e-3*I, box [0,%g], Phase-1 vertex "
+                                   "resident in HBM" % (args.config, P, N, batch.M, J, cfg.ub),
+                       "qps_per_gpu": P, "parallelism": "one QP per workgroup, batch sharded over %d GPU(s)" % world},
+            "iters_to_kkt": {"mean": float(iters.mean()), "max": int(iters.max()), "min": int(iters.min())},
+            "all_converged": ok,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "ssqp_solve_kernel", "kernel_ms": k_ms, "alg_bytes_per_launch": alg_bytes},
+            "setup_s": t_setup,
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pkg, prob, S0, x0, res, args.cpu_seconds, ncpu)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(pkg, prob, S0, x0, res, seconds, ncpu):
+    """The oracle (a C port of the reference algorithm, oracle/ssqp_oracle.c) timed on the host cores on a
+    bounded sample of the same workload (one QP per OpenMP thread, all cores of this process's affinity
+    mask); the same run is the parity check of that sample."""
+    from oracle import oracle as orc
+    P = prob["q"].shape[0]
+
+    def run(n, nthreads):
+        sub = [prob[k][:n] for k in "VAGqbgdu"]
+        t = time.perf_counter()
+        zo, So, sto, _, used = orc.solveQP_warm_batch(*sub, S0[:n], x0[:n], nthreads=nthreads)
+        return time.perf_counter() - t, zo, So, sto, used
+
+    probe_n = min(P, ncpu)
+    dt_probe, *_ = run(probe_n, ncpu)                       # also warms the library / thread pool
+    per_wave = max(dt_probe, 1e-3)                          # time of one "wave" of ncpu problems
+    n = int(min(P, max(probe_n, ncpu * round(seconds / per_wave))))
+    reps = int(max(1, min(8, round(seconds / max(per_wave * n / max(probe_n, 1), 1e-3)))))
+    total = 0.0
+    for _ in range(reps):
+        dt, zo, So, sto, used = run(n, ncpu)
+        total += dt
+    scale = np.maximum(np.abs(zo).max(axis=1), 1e-300)
+    rel = float((np.abs(res["z"][:n] - zo).max(axis=1) / scale).max())
+    return {"value": n * reps / total, "unit": "QPs/s", "cores": int(used), "kind": "port",
+            "sample": "first %d QPs of the same batch x %d repetitions, one QP per OpenMP thread, %.1f s of "
+                      "wall time" % (n, reps, total),
+            "parity_on_sample": {"S_bit_exact": bool(np.array_equal(res["S"][:n], So)),
+                                 "iters_equal": bool(np.array_equal(res["status"][:n], sto)),
+                                 "z_max_rel_err": rel}}
+
+
+if __name__ == "__main__":
+    main()

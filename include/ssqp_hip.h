@@ -127,7 +127,7 @@ int ssqp_solve_batch_f64(ssqp_ctx *ctx, int nprob, int N, int M, int J, const do
 
 /* Device-resident buffers (all pointers are device pointers on ctx's GPU;
  * stats/trace may be NULL).  Asynchronous on `stream` (a hipStream_t passed
- * as void*; NULL = the context's own stream); ssqp_sync waits for it.
+ * as void*; NULL = HIP's default stream); ssqp_sync waits for it.
  * trace holds ntrace records per problem. */
 int ssqp_solve_batch_dev_f64(ssqp_ctx *ctx, int nprob, int N, int M, int J, const double *dV,
                              const double *dA, const double *dG, const double *dq,

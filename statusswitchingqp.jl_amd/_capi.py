@@ -76,6 +76,13 @@ def lib():
             raise ImportError(
                 "libssqp_hip.so is not built (%s). Run `python __graft_entry__.py build`; "
                 "there is no CPU fallback." % LIB_PATH)
+        # PyTorch-ROCm bundles its own libamdhip64.so.7.  Two HIP runtimes in one process do not
+        # both see the GPU, so when torch is present it is imported FIRST: the loader then binds
+        # this library's NEEDED libamdhip64.so.7 to the copy torch already loaded.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(_lib, name)

@@ -118,7 +118,7 @@ const char *ssqp_last_error(const ssqp_ctx *c) { return c ? c->err.c_str() : "nu
 
 int ssqp_sync(ssqp_ctx *c, void *stream) {
     if (!c) return SSQP_ERR_ARG;
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;  // NULL is HIP's default stream, as everywhere in HIP
     return hip_ok(c, hipStreamSynchronize(s), "hipStreamSynchronize") ? SSQP_OK : SSQP_ERR_HIP;
 }
 
@@ -149,7 +149,7 @@ int ssqp_solve_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const 
     ssqp_default_settings(&def);
     const ssqp_settings *st = settings ? settings : &def;
     if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return SSQP_ERR_HIP;
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;  // NULL is HIP's default stream (what torch uses unless told otherwise)
 
     const int MJ = M + J;
     int grid = nprob < c->numCU ? nprob : c->numCU;

@@ -42,15 +42,27 @@ int generate_one(const ssqp_gen_cfg &c, uint64_t seed, double *V, double *A, dou
     // V = X'X/T + delta*I; X[t,i] = u01(t + T*i) - 1/2.  The sum over t runs in
     // increasing t for every (i,j): rank-1 accumulation, row t at a time.
     {
-        std::vector<double> xt(N);
+        // blocks of TB sample rows per sweep over V; per element the products are still added
+        // one at a time in increasing t (bit-identical to the unblocked rank-1 accumulation)
+        constexpr int TB = 16;
+        std::vector<double> xt((size_t)TB * N);
         const uint64_t bx = stream_base(seed, STREAM_X);
         std::fill(V, V + (size_t)N * N, 0.0);
-        for (int t = 0; t < T; ++t) {
-            for (int i = 0; i < N; ++i) xt[i] = u01(bx, (uint64_t)t + (uint64_t)T * i) - 0.5;
+        for (int t0 = 0; t0 < T; t0 += TB) {
+            const int tb = std::min(TB, T - t0);
+            for (int tt = 0; tt < tb; ++tt)
+                for (int i = 0; i < N; ++i)
+                    xt[(size_t)tt * N + i] = u01(bx, (uint64_t)(t0 + tt) + (uint64_t)T * i) - 0.5;
+            const double *__restrict__ xb = xt.data();
             for (int j = 0; j < N; ++j) {
-                const double xj = xt[j];
-                double *col = V + (size_t)j * N;
-                for (int i = 0; i <= j; ++i) col[i] += xt[i] * xj;  // upper triangle
+                double *__restrict__ col = V + (size_t)j * N;
+                double xj[TB];
+                for (int tt = 0; tt < tb; ++tt) xj[tt] = xb[(size_t)tt * N + j];
+                for (int i = 0; i <= j; ++i) {  // upper triangle; vectorises over i
+                    double s = col[i];
+                    for (int tt = 0; tt < tb; ++tt) s += xb[(size_t)tt * N + i] * xj[tt];
+                    col[i] = s;
+                }
             }
         }
         for (int j = 0; j < N; ++j) {
