@@ -67,17 +67,10 @@ def main():
     P, N, J = batch.P, batch.N, batch.J
     stream = torch.cuda.current_stream(dev)
 
-    if world > 1:
-        gz = torch.empty((world * P, N), dtype=torch.float64, device=dev)
-        gS = torch.empty((world * P, N + J), dtype=torch.int32, device=dev)
-        gst = torch.empty((world * P,), dtype=torch.int64, device=dev)
-
     def step():
         batch.solve()                       # in-kernel active-set loop, asynchronous on torch's stream
         if world > 1:                       # final gather of the sharded batch (RCCL over xGMI)
-            dist.all_gather_into_tensor(gz, batch.z)
-            dist.all_gather_into_tensor(gS, batch.S)
-            dist.all_gather_into_tensor(gst, batch.status)
+            pkg.dist.gather_results(batch.z, batch.S, batch.status)
 
     def fence():
         if world > 1:
@@ -102,16 +95,27 @@ def main():
     res = batch.results()
     ok = bool((res["status"] > 0).all())
     stats = res["stats"]
-    alg_bytes = int(stats["alg_bytes"].sum())
+    read_bytes = int(stats["read_bytes"].sum())     # bytes this kernel's formulation has to read
+    dense_bytes = int(stats["alg_bytes"].sum())     # bytes of the reference's dense formulation
     iters = res["status"].astype(np.int64)
 
     # a few more launches, each timed by its own HIP events, for the roofline figure
-    kms = []
-    for _ in range(3):
-        batch.solve()
-        torch.cuda.synchronize(dev)
-        kms.append(ctx.last_kernel_ms())
-    k_ms = float(np.mean(kms + [last_kernel_ms]))
+    def timed_launches(n):
+        ms = []
+        for _ in range(n):
+            batch.solve()
+            torch.cuda.synchronize(dev)
+            ms.append(ctx.last_kernel_ms())
+        return ms
+    k_ms = float(np.mean(timed_launches(3) + [last_kernel_ms]))
+    # the same kernel with the gamma pass reading EVERY column of V, as the reference's dense
+    # V[B,F]*alpha + V[B,B]*zB does (SSQP.jl:352): the HBM-bound formulation, timed beside the default one
+    os.environ["SSQP_DENSE_GAMMA"] = "1"
+    dense_ms = float(np.mean(timed_launches(2)))
+    res_dense = batch.results()
+    dense_same = bool(np.array_equal(res_dense["S"], res["S"]) and np.array_equal(res_dense["status"], res["status"]))
+    dense_read = int(res_dense["stats"]["read_bytes"].sum())
+    os.environ["SSQP_DENSE_GAMMA"] = "0"
 
     traffic = None
     if os.path.exists(args.traffic_json):
@@ -126,7 +130,8 @@ def main():
     out = None
     if rank == 0:
         qps = world * P * args.steps / elapsed
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        achieved = read_bytes / (k_ms * 1e-3) / 1e9
+        dense_achieved = dense_read / (dense_ms * 1e-3) / 1e9
         out = {
             "metric": "QPs/sec (batched N=512 dense portfolio QP, solveQP(Q,S,x0) to KKT)",
             "value": qps, "unit": "QPs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -139,7 +144,15 @@ def main():
             "all_converged": ok,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "ssqp_solve_kernel", "kernel_ms": k_ms, "alg_bytes_per_launch": alg_bytes},
+                         "kernel": "ssqp_solve_kernel", "kernel_ms": k_ms, "alg_bytes_per_launch": read_bytes,
+                         "note": "default formulation skips the columns of V whose weight in the gamma pass is "
+                                 "exactly 0 (bound variables at d=0): the loop is latency-bound, not HBM-bound"},
+            "roofline_dense_formulation": {
+                "bound": "hbm", "achieved": dense_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dense_achieved / HBM_PEAK_GBS, "kernel_ms": dense_ms, "alg_bytes_per_launch": dense_read,
+                "reference_formula_bytes": dense_bytes, "same_S_and_iters": dense_same,
+                "qps": P / (dense_ms * 1e-3),
+                "note": "same kernel, SSQP_DENSE_GAMMA=1: gamma pass reads all N columns like SSQP.jl:352"},
             "setup_s": t_setup,
         }
         if not args.no_cpu and world == 1:

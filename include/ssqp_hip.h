@@ -72,7 +72,9 @@ typedef struct ssqp_settings {
  * SURVEY.md section 8(d)): sums over the iterations the problem ran */
 typedef struct ssqp_stats {
     int64_t iters;      /* loop passes (== status when status > 0) */
-    int64_t alg_bytes;  /* sum_i 8(K^2+RK+R^2) + 8(M+J)N + 48N + 4(N+J) */
+    int64_t alg_bytes;  /* dense formulation: sum_i 8(K^2+RK[+R^2]) + 8(M+J)N + 48N + 4(N+J) */
+    int64_t read_bytes; /* this kernel's formulation: sum_i 8N(K + C_i) + 8(M+J)N + 48N + 4(N+J), C_i = columns
+                           of V with a nonzero weight in the gamma pass (0 when the step was blocked) */
     int64_t alg_flops;  /* sum_i K^3 + 4K^2W + 2K^2 + 2R^2 + 4RK + ... */
     int64_t sum_k3;     /* sum_i K^3 */
     int32_t max_k;      /* largest free set seen */

@@ -6,7 +6,7 @@ loop of PharosAbad/StatusSwitchingQP.jl, behind the reference's own surface:
 The directory name contains a dot, so it is loaded through
 `__graft_entry__.load_package()` (importlib) under the module name `ssqp_amd`.
 """
-from . import _capi
+from . import _capi, dist
 from ._capi import LIB_PATH, NoDeviceError, SSQPError
 from .solver import (BASE_SEED, CONFIGS, Context, DeviceBatch, GenConfig, default_context, generate_batch,
                      phase1_batch, solveQP, solveQP_batch)

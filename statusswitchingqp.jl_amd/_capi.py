@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libssqp_hip.so")
+# SSQP_HIP_LIB selects another build of the same library (e.g. the phase-profile diagnostic build)
+LIB_PATH = os.environ.get("SSQP_HIP_LIB") or os.path.join(_HERE, "libssqp_hip.so")
 
 OK, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_UNSUPPORTED = range(6)
 
@@ -26,7 +27,8 @@ class CSettings(C.Structure):
 
 
 class CStats(C.Structure):
-    _fields_ = [("iters", C.c_int64), ("alg_bytes", C.c_int64), ("alg_flops", C.c_int64), ("sum_k3", C.c_int64),
+    _fields_ = [("iters", C.c_int64), ("alg_bytes", C.c_int64), ("read_bytes", C.c_int64), ("alg_flops", C.c_int64),
+                ("sum_k3", C.c_int64),
                 ("max_k", C.c_int32), ("path", C.c_int32)]
 
 

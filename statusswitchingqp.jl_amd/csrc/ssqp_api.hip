@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -152,7 +153,26 @@ int ssqp_solve_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const 
     hipStream_t s = (hipStream_t)stream;  // NULL is HIP's default stream (what torch uses unless told otherwise)
 
     const int MJ = M + J;
-    int grid = nprob < c->numCU ? nprob : c->numCU;
+    // workgroups per CU: LDS is the limit.  3 when the N-vectors leave a useful arena in 1/3 of the 160 KiB,
+    // else 2, else 1 (SSQP_WG_PER_CU overrides for experiments).  A pass whose factor does not fit the LDS
+    // arena runs on the per-workgroup global arena instead, so any choice is correct.
+    const int fixed = ssqp::lds_fixed_bytes(N, M, J);
+    int wgPerCU = 1;
+    for (int w = 2; w >= 1; --w) {  // 3 per CU costs register spills at 168 VGPRs and measured slower
+        const int per = (ssqp::LDS_BYTES / w) / 1024 * 1024;
+        if (per - fixed >= 32 * 1024 || w == 1) {
+            wgPerCU = w;
+            break;
+        }
+    }
+    if (const char *e = getenv("SSQP_WG_PER_CU")) {
+        const int w = atoi(e);
+        if (w >= 1 && w <= ssqp::MAX_WG_PER_CU) wgPerCU = w;
+    }
+    if (N > 512 && (N & 1) == 0) wgPerCU = 1;  // the wide-accumulator kernels are built for one workgroup per CU
+    const int ldsPerWG = (ssqp::LDS_BYTES / wgPerCU) / 1024 * 1024;
+    int grid = c->numCU * wgPerCU;
+    if (grid > nprob) grid = nprob;
     if (grid < 1) grid = 1;
     const size_t gstride = ssqp::global_arena_doubles(N, M, J);
     if (!ensure(c, c->Ct, (size_t)nprob * MJ * N * 8) || !ensure(c, c->rhs, (size_t)nprob * MJ * 8) ||
@@ -172,8 +192,12 @@ int ssqp_solve_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const 
     P.queue = (unsigned int *)c->queue.p;
     P.gscratch = (double *)c->gscratch.p;
     P.gscratchStride = gstride;
-    const int fixed = ssqp::lds_fixed_bytes(N, M, J);
-    P.arenaCap = ((ssqp::LDS_BYTES - fixed - 64) / 16) * 2;
+    {
+        const char *e = getenv("SSQP_DENSE_GAMMA");
+        P.denseGamma = (e && atoi(e) != 0) ? 1 : 0;
+    }
+    P.arenaCap = ((ldsPerWG - fixed - 64) / 16) * 2;
+    if (P.arenaCap < 0) P.arenaCap = 0;
     const ssqp::LdsLayout lay = ssqp::lds_layout(N, M, J, P.arenaCap);
     if (lay.total_bytes > ssqp::LDS_BYTES) {
         c->err = "internal: LDS layout overflow";
@@ -184,7 +208,7 @@ int ssqp_solve_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const 
     ssqp::launch_prep(nprob, N, M, J, dA, dG, db, dg, (double *)c->Ct.p, (double *)c->rhs.p, s);
     if (!hip_ok(c, hipGetLastError(), "prep launch")) return SSQP_ERR_HIP;
     if (!hip_ok(c, hipEventRecord(c->ev0, s), "hipEventRecord")) return SSQP_ERR_HIP;
-    if (!hip_ok(c, ssqp::launch_solve(P, grid, (size_t)lay.total_bytes, s), "solve launch")) return SSQP_ERR_HIP;
+    if (!hip_ok(c, ssqp::launch_solve(P, grid, (size_t)lay.total_bytes, wgPerCU, s), "solve launch")) return SSQP_ERR_HIP;
     if (!hip_ok(c, hipEventRecord(c->ev1, s), "hipEventRecord")) return SSQP_ERR_HIP;
     c->timed = true;
     return SSQP_OK;

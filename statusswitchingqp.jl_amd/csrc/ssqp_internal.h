@@ -11,10 +11,13 @@
 
 namespace ssqp {
 
-constexpr int NT = 512;          // threads per workgroup (8 wavefronts of 64)
+constexpr int NT = 256;          // threads per workgroup (4 wavefronts of 64: one per SIMD)
 constexpr int NW = NT / 64;      // wavefronts per workgroup
-constexpr int MAXPT = 4;         // per-thread slots over the free list
+constexpr int MAXPT = 8;         // per-thread slots over the free list
 constexpr int MAXN = NT * MAXPT; // largest N the in-kernel loop accepts (2048)
+// up to 3 workgroups per CU (3 waves per SIMD -> at most 168 VGPRs): one streams V while the others
+// are in their latency-bound phases (factorisation, reductions)
+constexpr int MAX_WG_PER_CU = 3;
 constexpr int LDS_BYTES = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup may use all
 
 struct SolveParams {
@@ -36,6 +39,7 @@ struct SolveParams {
     double *gscratch;        // per-workgroup global arena (used when the LDS arena is too small)
     size_t gscratchStride;   // doubles per workgroup
     int arenaCap;            // doubles in the LDS arena
+    int denseGamma;          // 1: the gamma pass reads every column of V (dense formulation, for roofline runs)
 };
 
 // Offsets of the LDS carve-up.  Double-typed regions first (offsets in
@@ -54,7 +58,7 @@ __host__ __device__ inline int lds_fixed_bytes(int N, int M, int J) {
     int dbl = 3 * align_up(N, 2) + 5 * MJ1 + 2 * NW;
     int bytes = dbl * 8;
     bytes += align_up(4 * (N + J), 8);           // S
-    bytes += align_up(4 * (2 * NW + 8), 8);      // ired
+    bytes += align_up(4 * (2 * NW + 16), 8);     // ired
     bytes += 3 * align_up(2 * (N + 2), 8);       // pos, idx, perm
     bytes += 3 * align_up(2 * (M + J + 2), 8);   // rowsE, ra, iO
     return bytes;
@@ -76,7 +80,7 @@ __host__ __device__ inline LdsLayout lds_layout(int N, int M, int J, int arenaCa
     l.arena = o; o += align_up(arenaCap, 2);
     int b = o * 8;
     l.S_bytes = b; b += align_up(4 * (N + J), 8);
-    l.ired_bytes = b; b += align_up(4 * (2 * NW + 8), 8);
+    l.ired_bytes = b; b += align_up(4 * (2 * NW + 16), 8);
     l.pos_bytes = b; b += align_up(2 * (N + 2), 8);
     l.idx_bytes = b; b += align_up(2 * (N + 2), 8);
     l.perm_bytes = b; b += align_up(2 * (N + 2), 8);
@@ -90,15 +94,17 @@ __host__ __device__ inline LdsLayout lds_layout(int N, int M, int J, int arenaCa
 // doubles one workgroup may need in the global arena (K = N, W0 = M+J)
 inline size_t global_arena_doubles(int N, int M, int J) {
     const size_t K = N, W0 = M + J, R = K + W0 + 1;
-    const size_t packed = K * R - K * (K - 1) / 2;
+    const size_t packed = R * (R + 1) / 2;
     const size_t x = W0 * (K + 1) + W0;
-    const size_t f = packed + K + W0 * W0 + 2 * K + 64;
+    const size_t ls = K * W0 + W0 * W0 + W0;
+    size_t f = (packed + R > ls ? packed + R : ls) + 64;
+    if (f < (size_t)NW * N + 64) f = (size_t)NW * N + 64;   // staging of the AXPY partial vectors
     return (x > f ? x : f) + 64;
 }
 
 void launch_prep(int nprob, int N, int M, int J, const double *A, const double *G, const double *b,
                  const double *g, double *Ct, double *rhs, hipStream_t stream);
-hipError_t launch_solve(const SolveParams &P, int grid, size_t ldsBytes, hipStream_t stream);
+hipError_t launch_solve(const SolveParams &P, int grid, size_t ldsBytes, int wgPerCU, hipStream_t stream);
 
 }  // namespace ssqp
 #endif

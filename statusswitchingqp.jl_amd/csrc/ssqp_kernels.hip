@@ -49,15 +49,58 @@ __device__ __forceinline__ double sub_mul_nc(double x, double d, double y) {
     return x - t;
 }
 
+// ---- diagnostic build only (-DSSQP_PHASE_PROFILE): cycles per phase, thread 0 of each workgroup ----
+#ifdef SSQP_PHASE_PROFILE
+__device__ unsigned long long g_phase[1024 * 16];
+#define PHASE(C, n)                                                        \
+    do {                                                                   \
+        if (threadIdx.x == 0) {                                            \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();    \
+            g_phase[(blockIdx.x & 1023) * 16 + (C).ph_cur] += t_ - (C).ph_last; \
+            (C).ph_last = t_;                                              \
+            (C).ph_cur = (n);                                              \
+        }                                                                  \
+    } while (0)
+#else
+#define PHASE(C, n) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------- reductions
+// Wavefront reductions on DPP (data-parallel primitives: lane permutes inside the VALU, no LDS round
+// trip): xor-1 and xor-2 by quad_perm, then row_half_mirror and row_mirror complete a 16-lane row; the two
+// cross-row steps use the 64-lane shuffle.  Every lane ends with the result.  All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7-i inside each 8 lanes
+constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15-i inside each 16 lanes
+
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += dpp_f64<DPP_XOR1>(v);
+    v += dpp_f64<DPP_XOR2>(v);
+    v += dpp_f64<DPP_HALF_MIRROR>(v);
+    v += dpp_f64<DPP_MIRROR>(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    v = fmax(v, dpp_f64<DPP_XOR1>(v));
+    v = fmax(v, dpp_f64<DPP_XOR2>(v));
+    v = fmax(v, dpp_f64<DPP_HALF_MIRROR>(v));
+    v = fmax(v, dpp_f64<DPP_MIRROR>(v));
+    v = fmax(v, __shfl_xor(v, 16, 64));
+    v = fmax(v, __shfl_xor(v, 32, 64));
     return v;
 }
 
@@ -68,9 +111,20 @@ struct KeyMin {  // minimum value, ties -> smallest order
 __device__ __forceinline__ KeyMin keymin(KeyMin a, KeyMin b) {
     return (b.v < a.v || (b.v == a.v && b.ord < a.ord)) ? b : a;
 }
+template <int CTRL>
+__device__ __forceinline__ KeyMin keymin_dpp(KeyMin a) {
+    KeyMin b;
+    b.v = dpp_f64<CTRL>(a.v);
+    b.ord = dpp_i32<CTRL>(a.ord);
+    return keymin(a, b);
+}
 __device__ __forceinline__ KeyMin wave_keymin(KeyMin a) {
+    a = keymin_dpp<DPP_XOR1>(a);
+    a = keymin_dpp<DPP_XOR2>(a);
+    a = keymin_dpp<DPP_HALF_MIRROR>(a);
+    a = keymin_dpp<DPP_MIRROR>(a);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 16; o <= 32; o <<= 1) {
         KeyMin b;
         b.v = __shfl_xor(a.v, o, 64);
         b.ord = __shfl_xor(a.ord, o, 64);
@@ -136,7 +190,7 @@ __device__ __forceinline__ void dot2_cols(const double *__restrict__ c0, const d
                                           const double *w, int N, int lane, double &a0, double &a1) {
     a0 = 0.0;
     a1 = 0.0;
-    if (VEC == 2) {
+    if (VEC >= 2) {
 #pragma unroll 4
         for (int r = lane * 2; r < N; r += 128) {
             const double2 v0 = *reinterpret_cast<const double2 *>(c0 + r);
@@ -166,7 +220,7 @@ __device__ __forceinline__ void dot2_cols_gather(const double *__restrict__ c0, 
                                                  double &a0, double &a1) {
     a0 = 0.0;
     a1 = 0.0;
-    if (VEC == 2) {
+    if (VEC >= 2) {
 #pragma unroll 4
         for (int r = lane * 2; r < N; r += 128) {
             const double2 v0 = *reinterpret_cast<const double2 *>(c0 + r);
@@ -198,43 +252,118 @@ __device__ __forceinline__ void dot2_cols_gather(const double *__restrict__ c0, 
     }
 }
 
-// out[col] = V[:,col] . w   for the n columns listed in cols (stride cstep:
-// +1 walks the free list from the front, -1 walks the bound list from the back)
+// Partial dot products of four V columns with the LDS vector w: 16 independent
+// 16-byte loads per lane in flight at N = 512 (4 KiB per wave instruction group).
+template <int VEC>
+__device__ __forceinline__ void dot4_cols(const double *__restrict__ c0, const double *__restrict__ c1,
+                                          const double *__restrict__ c2, const double *__restrict__ c3,
+                                          const double *w, int N, int lane, double (&a)[4]) {
+    a[0] = a[1] = a[2] = a[3] = 0.0;
+    if (VEC >= 2) {
+#pragma unroll 4
+        for (int r = lane * 2; r < N; r += 128) {
+            const double2 v0 = *reinterpret_cast<const double2 *>(c0 + r);
+            const double2 v1 = *reinterpret_cast<const double2 *>(c1 + r);
+            const double2 v2 = *reinterpret_cast<const double2 *>(c2 + r);
+            const double2 v3 = *reinterpret_cast<const double2 *>(c3 + r);
+            const double2 ww = *reinterpret_cast<const double2 *>(w + r);
+            a[0] = fma(v0.y, ww.y, fma(v0.x, ww.x, a[0]));
+            a[1] = fma(v1.y, ww.y, fma(v1.x, ww.x, a[1]));
+            a[2] = fma(v2.y, ww.y, fma(v2.x, ww.x, a[2]));
+            a[3] = fma(v3.y, ww.y, fma(v3.x, ww.x, a[3]));
+        }
+    } else {
+#pragma unroll 4
+        for (int r = lane; r < N; r += 64) {
+            const double ww = w[r];
+            a[0] = fma(c0[r], ww, a[0]);
+            a[1] = fma(c1[r], ww, a[1]);
+            a[2] = fma(c2[r], ww, a[2]);
+            a[3] = fma(c3[r], ww, a[3]);
+        }
+    }
+}
+
+// out[col] = V[:,col] . w  for n columns.  cols == nullptr: columns 0..n-1; else the listed ones
+// (stride cstep: -1 walks the bound list from the back of idx).
 template <int VEC>
 __device__ __forceinline__ void stream_cols(const double *__restrict__ V, int N, const int16_t *cols,
                                             int cstep, int n, const double *w, double *out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int t = wave * 2; t < n; t += NW * 2) {
-        const bool two = (t + 1 < n);
-        const int j0 = cols[t * cstep];
-        const int j1 = two ? cols[(t + 1) * cstep] : j0;
-        double a0, a1;
-        dot2_cols<VEC>(V + (size_t)j0 * N, V + (size_t)j1 * N, w, N, lane, a0, a1);
-        a0 = wave_sum(a0);
-        a1 = wave_sum(a1);
+    for (int t = wave * 4; t < n; t += NW * 4) {
+        int j[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int tc = (t + c < n) ? t + c : t;
+            j[c] = cols ? (int)cols[tc * cstep] : tc;
+        }
+        double a[4];
+        dot4_cols<VEC>(V + (size_t)j[0] * N, V + (size_t)j[1] * N, V + (size_t)j[2] * N, V + (size_t)j[3] * N, w, N,
+                       lane, a);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] = wave_sum(a[c]);
         if (lane == 0) {
-            out[j0] = a0;
-            if (two) out[j1] = a1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (t + c < n) out[j[c]] = a[c];
         }
     }
 }
-template <int VEC>
-__device__ __forceinline__ void stream_all_cols(const double *__restrict__ V, int N, const double *w,
-                                                double *out) {
+
+// out = V[:, nz] * w[nz] in AXPY form: every lane owns fixed rows (the 16 bytes it loads from each 1 KiB
+// slice of a column) and accumulates them in registers over the columns its wavefront takes; no cross-lane
+// reduction.  Columns whose weight is exactly 0.0 are not in the list `nzl` and are never read (they would
+// add exact zeros), which is what makes the gamma pass cheap on portfolio problems where most bound
+// variables sit at d = 0.  The NW per-wave partial vectors are summed in wave order through `stage`
+// (NW*N doubles), so the result is deterministic.  N even (16-byte loads), N <= 128*NCH.
+template <int NCH, int NCOL>
+__device__ __forceinline__ void stream_axpy(const double *__restrict__ V, int N, const int16_t *nzl, int nnz,
+                                            const double *w, double *stage, double *out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int t = wave * 2; t < N; t += NW * 2) {
-        const bool two = (t + 1 < N);
-        const int j0 = t, j1 = two ? t + 1 : t;
-        double a0, a1;
-        dot2_cols<VEC>(V + (size_t)j0 * N, V + (size_t)j1 * N, w, N, lane, a0, a1);
-        a0 = wave_sum(a0);
-        a1 = wave_sum(a1);
-        if (lane == 0) {
-            out[j0] = a0;
-            if (two) out[j1] = a1;
+    double2 acc[NCH];
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) acc[m] = make_double2(0.0, 0.0);
+    for (int t = wave * NCOL; t < nnz; t += NW * NCOL) {
+        const double *__restrict__ col[NCOL];
+        double wj[NCOL];
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) {
+            const bool live = (t + c < nnz);
+            const int j = nzl[live ? t + c : t];
+            col[c] = V + (size_t)j * N;
+            wj[c] = live ? w[j] : 0.0;
+        }
+#pragma unroll
+        for (int m = 0; m < NCH; ++m) {
+            const int r = lane * 2 + 128 * m;
+            if (r < N) {
+                double2 v[NCOL];
+#pragma unroll
+                for (int c = 0; c < NCOL; ++c) v[c] = *reinterpret_cast<const double2 *>(col[c] + r);
+#pragma unroll
+                for (int c = 0; c < NCOL; ++c) {
+                    acc[m].x = fma(v[c].x, wj[c], acc[m].x);
+                    acc[m].y = fma(v[c].y, wj[c], acc[m].y);
+                }
+            }
         }
     }
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        const int r = lane * 2 + 128 * m;
+        if (r < N) *reinterpret_cast<double2 *>(stage + (size_t)wave * N + r) = acc[m];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += NT) {
+        double s = stage[i];
+#pragma unroll
+        for (int wv = 1; wv < NW; ++wv) s += stage[(size_t)wv * N + i];
+        out[i] = s;
+    }
 }
+
+// list of the indices with w[i] != 0 (all indices when `dense`), increasing; returns the count
+__device__ __forceinline__ int compact_nonzero(const double *w, int N, bool dense, int16_t *list, const Lds &L);
 
 // ------------------------------------------------------------- compaction
 // pos[i] = rank of i among the free variables or -1; idx[0..K) = free indices
@@ -271,6 +400,47 @@ __device__ __forceinline__ int compact_free(const Lds &L, int N) {
         __syncthreads();
     }
     return base;
+}
+
+__device__ __forceinline__ int compact_nonzero(const double *w, int N, bool dense, int16_t *list, const Lds &L) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int base = 0;
+    for (int c0 = 0; c0 < N; c0 += NT) {
+        const int i = c0 + threadIdx.x;
+        const bool f = (i < N) && (dense || w[i] != 0.0);
+        const unsigned long long m = __ballot(f);
+        const int lp = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) L.ired[wave] = __popcll(m);
+        __syncthreads();
+        int wb = 0, tot = 0;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) {
+            const int c = L.ired[wv];
+            if (wv < wave) wb += c;
+            tot += c;
+        }
+        if (f) list[base + wb + lp] = (int16_t)i;
+        base += tot;
+        __syncthreads();
+    }
+    return base;
+}
+
+// out = V * w restricted to the columns with nonzero weight: AXPY form for even N, dot form otherwise
+template <int VEC>
+__device__ __forceinline__ int stream_matvec(const double *__restrict__ V, int N, const double *w, bool dense,
+                                             double *stage, double *out, const Lds &L) {
+    // VEC: 1 scalar loads (odd N); 2, 3, 4: 16-byte loads with N <= 512, 1024, 2048 (register slots per lane)
+    if (VEC >= 2) {
+        const int nnz = compact_nonzero(w, N, dense, L.perm, L);
+        if (VEC == 2) stream_axpy<4, 4>(V, N, L.perm, nnz, w, stage, out);
+        else if (VEC == 3) stream_axpy<8, 2>(V, N, L.perm, nnz, w, stage, out);
+        else stream_axpy<16, 1>(V, N, L.perm, nnz, w, stage, out);
+        return nnz;
+    } else {
+        stream_cols<VEC>(V, N, nullptr, 1, N, w, out);
+        return N;
+    }
 }
 
 // ------------------------------------------------- getRowsGJr (utils.jl:49-86)
@@ -334,15 +504,79 @@ __device__ __forceinline__ int rank_filter(double *X, int W0, int nc, double tol
     return nrows;
 }
 
+// The same filter run by ONE wavefront (no workgroup barriers): used when X is small, which is the
+// common case (a handful of active rows).  Executed by wave 0 only; returns the number of kept rows.
+__device__ __forceinline__ int rank_filter_wave(double *X, int W0, int nc, double tol, const Lds &L) {
+    const int lane = threadIdx.x & 63;
+    for (int t = lane; t < nc; t += 64) L.perm[t] = (int16_t)t;
+    wave_sync();
+    int i = 0, j = 0, nrows = 0;
+    while (i < W0 && j < nc) {
+        KeyMin best{1.0, 0x7fffffff};  // maximise |x| == minimise -|x|; 1.0 never wins
+        bool any = false;
+        for (int t = j + lane; t < nc; t += 64) {
+            const double v = -fabs(X[i + W0 * (int)L.perm[t]]);
+            if (!any || v < best.v) {
+                best.v = v;
+                best.ord = t;
+                any = true;
+            }
+        }
+        best = wave_keymin(best);
+        const double m = -best.v;
+        const int mj = best.ord;
+        if (!(m > tol)) {
+            i += 1;
+            continue;
+        }
+        if (lane == 0) {
+            L.ra[nrows] = (int16_t)i;
+            const int16_t t = L.perm[mj];
+            L.perm[mj] = L.perm[j];
+            L.perm[j] = t;
+        }
+        nrows += 1;
+        wave_sync();
+        const int n = L.perm[j];
+        const double dd = X[i + W0 * n];
+        wave_sync();
+        for (int t = j + lane; t < nc; t += 64) {
+            const int c = L.perm[t];
+            X[i + W0 * c] = X[i + W0 * c] / dd;
+        }
+        for (int k = lane; k < W0; k += 64) L.dcol[k] = X[k + W0 * n];
+        wave_sync();
+        if (W0 > 1) {
+            const int span = nc - j;
+            for (int e = lane; e < span * W0; e += 64) {
+                const int k = e % W0, t = j + e / W0;
+                if (k != i) {
+                    const int c = L.perm[t];
+                    X[k + W0 * c] = sub_mul_nc(X[k + W0 * c], L.dcol[k], X[i + W0 * c]);
+                }
+            }
+            wave_sync();
+        }
+        i += 1;
+        j += 1;
+    }
+    return nrows;
+}
+
 // --------------------------------------------------- bordered LDL' in the arena
-// fac: packed lower triangle of [V_FF; AE; c'] (R = K+W+1 rows, K columns).
-// After the call column j holds the unscaled eliminated entries a(i,j), rd[j] =
-// 1/d_j; unit-lower L(i,j) = a(i,j)*rd[j], border rows = L^-1 [AE' c].
-// Returns false when a pivot is not > 0 (the reference's cholesky throws).
-__device__ __forceinline__ bool bordered_ldl(double *fac, double *rd, int K, int R, const Lds &L) {
+// fac: packed lower triangle (column j holds rows j..R-1) of the R x R matrix
+//     [ V_FF  .   . ]      R = K + W + 1
+//     [ AE    0   . ]
+//     [ c'    0   0 ]
+// bordered_ldl eliminates columns jb..je-1 (right-looking, one barrier per column) and applies every
+// update to ALL later columns, border included.  After columns 0..K-1: column j holds the unscaled
+// entries a(i,j), rd[j] = 1/d_j, unit-lower L(i,j) = a(i,j)*rd[j]; the border rows of those columns are
+// L^-1 [AE' c], and the trailing (W+1) x (W+1) block is the Schur complement -[AE;c'] V_FF^-1 [AE' c].
+// Returns false when a pivot is not > 0 (where the reference's cholesky throws PosDefException).
+__device__ __forceinline__ bool bordered_ldl(double *fac, double *rd, int jb, int je, int R, const Lds &L) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool ok = true;
-    for (int j = 0; j < K; ++j) {
+    for (int j = jb; j < je; ++j) {
         __syncthreads();
         const int oj = coloff(j, R);
         const double d = fac[oj];
@@ -352,7 +586,7 @@ __device__ __forceinline__ bool bordered_ldl(double *fac, double *rd, int K, int
         }
         const double r = 1.0 / d;
         if (threadIdx.x == 0) rd[j] = r;
-        for (int k = j + 1 + wave; k < K; k += NW) {
+        for (int k = j + 1 + wave; k < R; k += NW) {
             const double f = fac[oj + k - j] * r;
             const int ok_ = coloff(k, R);
             for (int i = k + lane; i < R; i += 64) fac[ok_ + i - k] = fma(-f, fac[oj + i - j], fac[ok_ + i - k]);
@@ -362,14 +596,15 @@ __device__ __forceinline__ bool bordered_ldl(double *fac, double *rd, int K, int
     return ok;
 }
 
-// Solve the unit upper system L' x = v in place (v in vk[0..K)), one wave.
-__device__ __forceinline__ void back_substitute(const double *fac, const double *rd, double *vk, int K, int R) {
+// Solve the unit upper system L' x = v in place for the n columns j0..j0+n-1 (v[0..n)), one wavefront.
+__device__ __forceinline__ void back_substitute(const double *fac, const double *rd, double *v, int j0, int n,
+                                                int R) {
     const int lane = threadIdx.x & 63;
-    for (int j = K - 1; j > 0; --j) {
-        const double xj = vk[j];
+    for (int j = n - 1; j > 0; --j) {
+        const double xj = v[j];
         for (int i = lane; i < j; i += 64) {
-            const double lij = fac[coloff(i, R) + j - i] * rd[i];
-            vk[i] = fma(-lij, xj, vk[i]);
+            const double lij = fac[coloff(j0 + i, R) + j - i] * rd[j0 + i];
+            v[i] = fma(-lij, xj, v[i]);
         }
         wave_sync();
     }
@@ -387,11 +622,18 @@ struct ProbCtx {
     const double *__restrict__ uhi;
     ssqp_trace *trace;
     int ntrace;
+    int arenaCap;
+    bool dense;       // read zero-weight columns too (roofline measurement of the dense formulation)
+    double *garena;
     // results / accounting
     int64_t iter, ret;
     int32_t det;
-    int64_t sBytes, sFlops, sK3;
+    int64_t sBytes, sRead, sFlops, sK3;
     int maxK, pathBits;
+#ifdef SSQP_PHASE_PROFILE
+    unsigned long long ph_last;
+    int ph_cur;
+#endif
 };
 
 enum { ACT_CONTINUE = 0, ACT_BREAK = 1 };
@@ -412,10 +654,13 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     const double *__restrict__ uhi = C.uhi;
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
     const int R = N - K, JE = W0 - M;
+    // per-thread slots over the free list: N <= 512 needs 2 at 256 threads (VEC 2), N <= 1024 4, else 8
+    constexpr int MPT = (VEC == 2) ? 2 : ((VEC == 3) ? 4 : MAXPT);
     const int64_t iter = C.iter;
     ssqp_trace *trace = (C.trace && iter <= C.ntrace) ? C.trace + (iter - 1) : nullptr;
 
     // ---- E-row sweep: bE and X = [AE bE]   (SSQP.jl:290-295) ----
+    PHASE(C, 1);
     {
         double *X = ar;
         for (int w = wave; w < W0; w += NW) {
@@ -438,8 +683,20 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     }
     __syncthreads();
     // ---- rank filter  (SSQP.jl:310-319) ----
+    PHASE(C, 2);
     int W = W0;
-    if (W0 > 0) W = rank_filter(ar, W0, K + 1, tol, L);
+    if (W0 > 0) {
+        if ((long)W0 * (K + 1) <= 4096) {  // small: one wavefront, no workgroup barriers
+            if (wave == 0) {
+                const int w = rank_filter_wave(ar, W0, K + 1, tol, L);
+                if (lane == 0) L.ired[2 * NW + 4] = w;
+            }
+            __syncthreads();
+            W = L.ired[2 * NW + 4];
+        } else {
+            W = rank_filter(ar, W0, K + 1, tol, L);
+        }
+    }
     if (W < W0) {
         double v = 0.0;
         if (tid < W) v = L.bE[L.ra[tid]];
@@ -451,10 +708,10 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     __syncthreads();
 
     // ---- factor assembly: pass 1 over V[:,F] + border rows ----
+    PHASE(C, 3);
     const int Rr = K + W + 1;
     double *fac = ar;
-    double *rd = ar + coloff(K, Rr);
-    double *H = rd + K;  // W x W, column-major, lower part used
+    double *rd = ar + coloff(Rr, Rr);  // Rr reciprocal pivots behind the packed R x R triangle
     for (int t = wave * 2; t < K; t += NW * 2) {
         const bool two = (t + 1 < K);
         const int k0 = t, k1 = two ? t + 1 : t;
@@ -475,82 +732,53 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         const int r = L.rowsE[L.ra[w]];
         fac[coloff(k, Rr) + (K + w) - k] = Ct[(size_t)r * N + L.idx[k]];
     }
+    {  // zero border-border block (columns K..K+W are contiguous at the end of the packed triangle)
+        const int ob = coloff(K, Rr), ne = coloff(Rr, Rr) - ob;
+        for (int e = tid; e < ne; e += NT) fac[ob + e] = 0.0;
+    }
     // (barrier at the top of bordered_ldl)
-    if (!bordered_ldl(fac, rd, K, Rr, L)) {
+#ifdef SSQP_PHASE_PROFILE
+    __syncthreads();
+#endif
+    PHASE(C, 4);
+    if (!bordered_ldl(fac, rd, 0, K, Rr, L)) {
         C.ret = -1;
         C.det = SSQP_DETAIL_POSDEF_V;
         return ACT_BREAK;
     }
-    // ---- Schur system: H = AE V^-1 AE', t = AE V^-1 c ----
-    for (int e = wave; e < W * (W + 1) / 2 + W; e += NW) {
-        int a, b;  // border rows a >= b; a == W is the c row
-        if (e < W) {
-            a = W;
-            b = e;
-        } else {
-            int f = e - W, col = 0;
-            while (f >= W - col) {
-                f -= W - col;
-                ++col;
+    // ---- Schur system (AE V^-1 AE') lam = bE + AE V^-1 c ; alphaL = -lam  (SSQP.jl:325-328, 351) ----
+    PHASE(C, 5);
+    if (W > 0) {
+        // trailing block holds -H (W x W) and, in the c row, -t: flip the sign of H, put s = bE + t in the row
+        for (int e = tid; e < W * (W + 1) / 2 + W; e += NT) {
+            if (e < W) {
+                const int o = coloff(K + e, Rr) + (W - e);
+                fac[o] = L.bE[e] - fac[o];
+            } else {
+                int f = e - W, col = 0;
+                while (f >= W - col) {
+                    f -= W - col;
+                    ++col;
+                }
+                const int o = coloff(K + col, Rr) + f;
+                fac[o] = -fac[o];
             }
-            a = col + f;
-            b = col;
         }
-        double acc = 0.0;
-        for (int j = lane; j < K; j += 64) {
-            const int oj = coloff(j, Rr);
-            acc = fma(fac[oj + K + a - j] * rd[j], fac[oj + K + b - j], acc);
+        if (!bordered_ldl(fac, rd, K, K + W, Rr, L)) {
+            C.ret = -1;
+            C.det = SSQP_DETAIL_POSDEF_C;
+            return ACT_BREAK;
         }
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            if (e < W) L.tv[b] = acc;
-            else H[a + W * b] = acc;
-        }
-    }
-    __syncthreads();
-    // lambda: H lam = bE + t ; alphaL = -lam  (SSQP.jl:351, algebraically)
-    if (wave == 0) {
-        bool okH = true;
-        for (int c = 0; c < W; ++c) {  // in-place LDL' of H, lanes over rows
-            const double dcc = H[c + W * c];
-            if (!(dcc > 0.0)) {
-                okH = false;
-                break;
-            }
-            const double rc = 1.0 / dcc;
-            for (int k2 = c + 1; k2 < W; ++k2) {
-                const double f = H[k2 + W * c] * rc;
-                for (int i = k2 + lane; i < W; i += 64) H[i + W * k2] = fma(-f, H[i + W * c], H[i + W * k2]);
-            }
+        if (wave == 0) {
+            for (int w = lane; w < W; w += 64) L.aL[w] = fac[coloff(K + w, Rr) + (W - w)] * rd[K + w];
             wave_sync();
+            back_substitute(fac, rd, L.aL, K, W, Rr);
+            for (int w = lane; w < W; w += 64) L.aL[w] = -L.aL[w];
         }
-        if (lane == 0) {
-            L.ired[2 * NW + 2] = okH ? 1 : 0;
-            if (okH) {  // forward (unit lower), diagonal, backward: W is small
-                for (int w = 0; w < W; ++w) L.aL[w] = L.bE[w] + L.tv[w];
-                for (int c = 0; c < W; ++c) {
-                    const double xc = L.aL[c];
-                    const double rc = 1.0 / H[c + W * c];
-                    for (int i = c + 1; i < W; ++i) L.aL[i] = fma(-H[i + W * c] * rc, xc, L.aL[i]);
-                }
-                for (int c = 0; c < W; ++c) L.aL[c] = L.aL[c] / H[c + W * c];
-                for (int c = W - 1; c >= 0; --c) {
-                    double xc = L.aL[c];
-                    const double rc = 1.0 / H[c + W * c];
-                    for (int i = c + 1; i < W; ++i) xc = fma(-H[i + W * c] * rc, L.aL[i], xc);
-                    L.aL[c] = xc;
-                }
-                for (int w = 0; w < W; ++w) L.aL[w] = -L.aL[w];
-            }
-        }
-    }
-    __syncthreads();
-    if (!L.ired[2 * NW + 2]) {
-        C.ret = -1;
-        C.det = SSQP_DETAIL_POSDEF_C;
-        return ACT_BREAK;
+        __syncthreads();
     }
     // v = D^-1 (Y_A alphaL + y_c); alpha = -L'^-1 v
+    PHASE(C, 6);
     double *vk = L.gam;
     for (int j = tid; j < K; j += NT) {
         const int oj = coloff(j, Rr);
@@ -559,12 +787,13 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         vk[j] = s * rd[j];
     }
     __syncthreads();
-    if (wave == 0) back_substitute(fac, rd, vk, K, Rr);
+    if (wave == 0) back_substitute(fac, rd, vk, 0, K, Rr);
     __syncthreads();
     // ---- alpha (scattered into gam), p (scattered into zm) ----
-    double areg[MAXPT];
+    PHASE(C, 7);
+    double areg[MPT];
 #pragma unroll
-    for (int m = 0; m < MAXPT; ++m) {
+    for (int m = 0; m < MPT; ++m) {
         const int k = tid + m * NT;
         areg[m] = (k < K) ? -vk[k] : 0.0;
     }
@@ -574,7 +803,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     for (int i = tid; i < N; i += NT)
         if (L.pos[i] < 0) L.zm[i] = 0.0;
 #pragma unroll
-    for (int m = 0; m < MAXPT; ++m) {
+    for (int m = 0; m < MPT; ++m) {
         const int k = tid + m * NT;
         if (k < K) {
             const int i = L.idx[k];
@@ -592,10 +821,12 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     {
         const long long k = K, r = R, w = W;
         C.sBytes += 8ll * (k * k + r * k) + 8ll * MJ * N + 48ll * N + 4ll * (N + J);
+        C.sRead += 8ll * N * k + 8ll * MJ * N + 48ll * N + 4ll * (N + J);
         C.sFlops += k * k * k + 4 * k * k * w + 2 * k * k + 2 * r * k + 2ll * W0 * r + w * w * w;
         C.sK3 += k * k * k;
     }
 
+    PHASE(C, 8);
     if (pinf > tolG && !anyNan) {  // ------------------------ aStep!  SSQP.jl:61-134
         // inactive inequalities: zo = g - G z, po = G[:,F] p   (:78-89)
         for (int o = wave; o < JO; o += NW) {
@@ -613,9 +844,9 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         }
         __syncthreads();
         KeyMin ev{inf, 0};
-        double Lreg[MAXPT];
+        double Lreg[MPT];
 #pragma unroll
-        for (int m = 0; m < MAXPT; ++m) {
+        for (int m = 0; m < MPT; ++m) {
             const int k = tid + m * NT;
             Lreg[m] = inf;
             if (k < K) {
@@ -633,7 +864,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         if (L1 < 1.0) {  // blocked  (:98-127)
             int firstId = 0x7fffffff;
 #pragma unroll
-            for (int m = 0; m < MAXPT; ++m) {
+            for (int m = 0; m < MPT; ++m) {
                 const int k = tid + m * NT;
                 if (k < K) {
                     const int i = L.idx[k];
@@ -663,7 +894,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         }
         // full step: z[F] = alpha  (:130)
 #pragma unroll
-        for (int m = 0; m < MAXPT; ++m) {
+        for (int m = 0; m < MPT; ++m) {
             const int k = tid + m * NT;
             if (k < K) L.z[L.idx[k]] = areg[m];
         }
@@ -671,14 +902,22 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     __syncthreads();
 
     // ---- multipliers: gamma = V[B,F] alpha + V[B,B] zB + q[B] + AB' alphaL  (SSQP.jl:352) ----
+    PHASE(C, 9);
     for (int i = tid; i < N; i += NT) L.zm[i] = (L.pos[i] >= 0) ? L.gam[i] : L.z[i];
     __syncthreads();
-    stream_cols<VEC>(V, N, L.idx + (N - 1), -1, R, L.zm, L.gam);
+    {
+        // per-wave partial vectors go through the LDS arena when it has room (the factor is dead), else
+        // through the workgroup's global arena
+        double *stage = (INLDS && (long)NW * N <= C.arenaCap) ? ar : C.garena;
+        const int ncols = stream_matvec<VEC>(V, N, L.zm, C.dense, stage, L.gam, L);
+        C.sRead += 8ll * N * ncols;
+    }
     __syncthreads();
     C.sBytes += 8ll * R * R;
     C.sFlops += 2ll * R * R + 2ll * R * K;
 
     // ---- KKTchk!  SSQP.jl:136-188 ----
+    PHASE(C, 10);
     KeyMin ev{inf, 0x7fffffff};
     for (int i = tid; i < N; i += NT) {
         if (L.pos[i] >= 0) continue;
@@ -770,6 +1009,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         return ACT_CONTINUE;
     }
     // ---- optimal: polishSz!  SSQP.jl:10-32 ----
+    PHASE(C, 11);
     for (int i = tid; i < N; i += NT) {
         const int s = L.S[i];
         if (s == SSQP_DN) L.z[i] = dlo[i];
@@ -813,10 +1053,17 @@ __device__ void solve_one(const SolveParams &P, int prob, const Lds &L, double *
     C.uhi = P.u + (size_t)prob * N;
     C.trace = P.trace ? P.trace + (size_t)prob * P.ntrace : nullptr;
     C.ntrace = P.ntrace;
+    C.arenaCap = P.arenaCap;
+    C.dense = P.denseGamma != 0;
+    C.garena = garena;
     C.iter = 0; C.ret = 0; C.det = SSQP_DETAIL_NONE;
-    C.sBytes = 0; C.sFlops = 0; C.sK3 = 0; C.maxK = 0; C.pathBits = 0;
+    C.sBytes = 0; C.sRead = 0; C.sFlops = 0; C.sK3 = 0; C.maxK = 0; C.pathBits = 0;
     int32_t *Sg = P.S + (size_t)prob * (N + J);
     const double tol = P.tol;
+#ifdef SSQP_PHASE_PROFILE
+    C.ph_cur = 11;
+    C.ph_last = __builtin_amdgcn_s_memtime();
+#endif
 
     for (int i = tid; i < N; i += NT) L.z[i] = P.x0[(size_t)prob * N + i];
     for (int i = tid; i < N + J; i += NT) L.S[i] = Sg[i];
@@ -828,13 +1075,17 @@ __device__ void solve_one(const SolveParams &P, int prob, const Lds &L, double *
             C.ret = -C.iter;
             break;
         }
+        PHASE(C, 0);
         const int K = compact_free(L, N);
         ssqp_trace *trace = (C.trace && C.iter <= C.ntrace) ? C.trace + (C.iter - 1) : nullptr;
 
         if (K == 0) {  // ---------------------------------------- freeK!  SSQP.jl:35-59
+            PHASE(C, 12);
             for (int i = tid; i < N; i += NT) L.zm[i] = L.z[i];
             __syncthreads();
-            stream_all_cols<VEC>(C.V, N, L.zm, L.gam);
+            const int ncols = stream_matvec<VEC>(C.V, N, L.zm, C.dense,
+                                                 ((long)NW * N <= P.arenaCap) ? L.arena : garena, L.gam, L);
+            C.sRead += 8ll * N * ncols + 16ll * N + 4ll * (N + J);
             __syncthreads();
             int flag = 0;
             double pa = 0.0;
@@ -893,7 +1144,10 @@ __device__ void solve_one(const SolveParams &P, int prob, const Lds &L, double *
 
         // arena: LDS when [X | packed factor + Schur block] fits, else the global scratch
         const long needX = (long)W0 * (K + 1);
-        const long needF = (long)coloff(K, K + W0 + 1) + K + (long)W0 * W0 + W0 + 8;
+        const long R0 = K + W0 + 1;
+        long needF = R0 * (R0 + 1) / 2 + R0 + 8;
+        const long needLS = (long)K * W0 + (long)W0 * W0 + W0 + 8;
+        if (needLS > needF) needF = needLS;
         const bool inLds = (needX <= P.arenaCap) && (needF <= P.arenaCap);
         C.pathBits |= inLds ? 1 : 2;
         int act;
@@ -902,6 +1156,7 @@ __device__ void solve_one(const SolveParams &P, int prob, const Lds &L, double *
         if (act == ACT_BREAK) break;
     }
     __syncthreads();
+    PHASE(C, 11);
     for (int i = tid; i < N; i += NT) P.z[(size_t)prob * N + i] = L.z[i];
     for (int i = tid; i < N + J; i += NT) Sg[i] = L.S[i];
     if (tid == 0) {
@@ -911,6 +1166,7 @@ __device__ void solve_one(const SolveParams &P, int prob, const Lds &L, double *
             ssqp_stats st;
             st.iters = C.iter > P.maxIter ? P.maxIter : C.iter;
             st.alg_bytes = C.sBytes;
+            st.read_bytes = C.sRead;
             st.alg_flops = C.sFlops;
             st.sum_k3 = C.sK3;
             st.max_k = C.maxK;
@@ -918,11 +1174,30 @@ __device__ void solve_one(const SolveParams &P, int prob, const Lds &L, double *
             P.stats[prob] = st;
         }
     }
+    PHASE(C, 13);
     __syncthreads();
 }
 
-template <int VEC>
-__global__ __launch_bounds__(NT) void ssqp_solve_kernel(SolveParams P) {
+#ifdef SSQP_PHASE_PROFILE
+}  // namespace ssqp
+extern "C" int ssqp_debug_phases(unsigned long long *out16, int reset) {
+    static unsigned long long host[1024 * 16];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(ssqp::g_phase), sizeof(host)) != hipSuccess) return 1;
+    for (int k = 0; k < 16; ++k) out16[k] = 0;
+    for (int b = 0; b < 1024; ++b)
+        for (int k = 0; k < 16; ++k) out16[k] += host[b * 16 + k];
+    if (reset) {
+        static unsigned long long zero[1024 * 16];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ssqp::g_phase), zero, sizeof(zero)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+namespace ssqp {
+#endif
+
+// WPS = waves per SIMD the register allocation must allow = workgroups per CU (one wave per SIMD each)
+template <int VEC, int WPS>
+__global__ __launch_bounds__(NT, WPS) void ssqp_solve_kernel(SolveParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Lds L;
     {
@@ -990,20 +1265,25 @@ void launch_prep(int nprob, int N, int M, int J, const double *A, const double *
     hipLaunchKernelGGL(ssqp_prep_kernel, dim3(blocks), dim3(256), 0, stream, nprob, N, M, J, A, G, b, g, Ct, rhs);
 }
 
-hipError_t launch_solve(const SolveParams &P, int grid, size_t ldsBytes, hipStream_t stream) {
-    hipError_t e;
-    if ((P.N & 1) == 0) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ssqp_solve_kernel<2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(ssqp_solve_kernel<2>, dim3(grid), dim3(NT), ldsBytes, stream, P);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ssqp_solve_kernel<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(ssqp_solve_kernel<1>, dim3(grid), dim3(NT), ldsBytes, stream, P);
-    }
+template <int VEC, int WPS>
+static hipError_t launch_one(const SolveParams &P, int grid, size_t ldsBytes, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ssqp_solve_kernel<VEC, WPS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ssqp_solve_kernel<VEC, WPS>), dim3(grid), dim3(NT), ldsBytes, stream, P);
     return hipGetLastError();
+}
+
+hipError_t launch_solve(const SolveParams &P, int grid, size_t ldsBytes, int wgPerCU, hipStream_t stream) {
+    // load/accumulate mode: see stream_matvec
+    const int mode = (P.N & 1) ? 1 : (P.N <= 512 ? 2 : (P.N <= 1024 ? 3 : 4));
+    const bool three = wgPerCU >= 3;
+    switch (mode) {
+        case 1: return three ? launch_one<1, 3>(P, grid, ldsBytes, stream) : launch_one<1, 2>(P, grid, ldsBytes, stream);
+        case 2: return three ? launch_one<2, 3>(P, grid, ldsBytes, stream) : launch_one<2, 2>(P, grid, ldsBytes, stream);
+        case 3: return launch_one<3, 1>(P, grid, ldsBytes, stream);  // N > 512: one workgroup per CU, up to 512 VGPRs
+        default: return launch_one<4, 1>(P, grid, ldsBytes, stream);
+    }
 }
 
 }  // namespace ssqp

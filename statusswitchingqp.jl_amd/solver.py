@@ -190,7 +190,8 @@ def solveQP_batch(prob, S, x0, settings=None, ctx=None, want_stats=False):
     return z, S, status, detail
 
 
-STATS_DTYPE = np.dtype([("iters", "<i8"), ("alg_bytes", "<i8"), ("alg_flops", "<i8"), ("sum_k3", "<i8"),
+STATS_DTYPE = np.dtype([("iters", "<i8"), ("alg_bytes", "<i8"), ("read_bytes", "<i8"), ("alg_flops", "<i8"),
+                        ("sum_k3", "<i8"),
                         ("max_k", "<i4"), ("path", "<i4")])
 TRACE_DTYPE = np.dtype([("K", "<i4"), ("W", "<i4"), ("kind", "<i4"), ("id", "<i4")])
 

@@ -78,3 +78,93 @@ def test_trace_matches_oracle(pkg, orc):
         assert res["status"][p] == sto
         got = [tuple(int(v) for v in r) for r in res["trace"][p][:sto]]
         assert got == tr
+
+
+# ---------------------------------------------------------------- golden fixtures through the C ABI
+import glob
+import os
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_golden_fixture(pkg, path):
+    d = np.load(path)
+    c = {k: d[k] for k in d.files}
+    Q = pkg.QP.inner(c["V"], c["A"], c["G"], c["q"], c["b"], c["g"], c["d"], c["u"])
+    if int(c["phase1_status"]) != 1:
+        z, S, status = pkg.solveQP(Q)                 # full path: Phase-1 on the host reports infeasibility
+        assert status == 0
+        return
+    z, S, status = pkg.solveQP(Q)                     # solveQP(Q): Phase-1 + loop
+    assert status == int(c["status"]) and np.array_equal(S, c["S"])
+    np.testing.assert_allclose(z, c["z"], rtol=0, atol=1e-10 * max(1.0, np.abs(c["z"]).max()))
+    S2 = c["S0"].astype(np.int32).copy()              # solveQP(Q, S, x0): S is mutated in place and returned
+    z2, Sret, status2 = pkg.solveQP(Q, S2, c["x0"])
+    assert Sret is S2 and np.array_equal(S2, c["S"]) and status2 == int(c["status"])
+    # per-iteration trace (K, W, event kind, switched id) identical to the oracle's
+    prob = dict(V=c["V"][None], A=np.ascontiguousarray(c["A"].T)[None], G=np.ascontiguousarray(c["G"].T)[None],
+                q=c["q"][None], b=c["b"][None], g=c["g"][None], d=c["d"][None], u=c["u"][None])
+    db = pkg.DeviceBatch(prob, c["S0"][None], c["x0"][None], ntrace=4096)
+    db.solve()
+    r = db.results()
+    assert np.array_equal(r["trace"][0][:status], c["trace"])
+
+
+def test_status_codes_on_gpu(pkg):
+    d = np.load([p for p in GOLDEN if p.endswith("box20_j3.npz")][0])
+    c = {k: d[k] for k in d.files}
+    args = (c["A"], c["G"], c["q"], c["b"], c["g"], c["d"], c["u"])
+    Q = pkg.QP.inner(c["V"], *args, mc=-70)                                   # SSQP.jl:226-228
+    z, S, status, det = pkg.solveQP(Q, return_detail=True)
+    assert status == -1 and det == 4 and (S == pkg.DN).all() and len(S) == 20 and (z == 0).all()
+    Q = pkg.QP.inner(c["V"], *args)
+    z, S, status = pkg.solveQP(Q, c["S0"].astype(np.int32).copy(), c["x0"], settings=pkg.Settings(maxIter=5))
+    assert status == -6                                                       # SSQP.jl:272-273
+    Qbad = pkg.QP.inner(c["V"] - 10.0 * np.eye(20), *args)                    # cholesky(V[F,F]) would throw
+    z, S, status, det = pkg.solveQP(Qbad, c["S0"].astype(np.int32).copy(), c["x0"], return_detail=True)
+    assert status == -1 and det == 1
+
+
+# ---------------------------------------------------------------- full-size batches: properties
+def test_full_batch_properties_cfg4(pkg, orc):
+    """1024 x N=512 (BASELINE.json configs[3] per GPU): everything converges, a sample is bit-exact against the
+    oracle and passes the independent KKT check, and re-solving from the solution is a fixed point."""
+    from kkt import assert_kkt
+    cfg = pkg.CONFIGS["cfg4"]
+    prob = pkg.generate_batch(cfg, 1024)
+    x0, S0, st = pkg.phase1_batch(prob)
+    z, S, status, detail, stats = pkg.solveQP_batch(prob, S0, x0, want_stats=True)
+    assert (status > 0).all() and (detail == 0).all()
+    assert np.abs(z.sum(axis=1) - 1.0).max() < 1e-9 and z.min() >= 0.0 and z.max() <= cfg.ub   # feasibility
+    sel = np.arange(0, 1024, 16)
+    sub = {k: v[sel] for k, v in prob.items()}
+    zo, So, sto, _, _ = oracle_batch(orc, sub, S0[sel], x0[sel])
+    assert_parity(z[sel], S[sel], status[sel], zo, So, sto)
+    for p in sel[:8]:
+        assert_kkt(prob["V"][p], colmajor(prob["A"][p], cfg.M), colmajor(prob["G"][p], cfg.J), prob["q"][p],
+                   prob["b"][p], prob["g"][p], prob["d"][p], prob["u"][p], z[p], S[p])
+    # idempotence: warm start at the optimum leaves S unchanged and stops after one pass
+    z2, S2, status2, _ = pkg.solveQP_batch(prob, S, z)
+    assert np.array_equal(S2, S) and (status2 == 1).all() and np.abs(z2 - z).max() < 1e-9
+    # the dense formulation of the gamma pass (every column of V read, as SSQP.jl:352) takes the same decisions
+    os.environ["SSQP_DENSE_GAMMA"] = "1"
+    try:
+        z3, S3, status3, _ = pkg.solveQP_batch(prob, S0, x0)
+    finally:
+        os.environ["SSQP_DENSE_GAMMA"] = "0"
+    assert np.array_equal(S3, S) and np.array_equal(status3, status) and np.abs(z3 - z).max() < 1e-12
+
+
+def test_cfg5_rank_deficient_n2048(pkg, orc):
+    """BASELINE.json configs[4]: N=2048, M=8, J=64, V = X'X/T with T=1024 (rank 1024, no ridge).  The reference
+    only works while V[F,F] stays PD; on this instance it does (K <= 136)."""
+    cfg = pkg.CONFIGS["cfg5"]
+    rel, stats = run_cfg(pkg, orc, cfg, 1)
+    assert stats["max_k"][0] < 1024
+
+
+def test_batch_larger_than_grid(pkg, orc):
+    """more problems than resident workgroups: the work queue hands several problems to one workgroup"""
+    cfg = pkg.GenConfig(96, 1, 4, 192, 1e-3, 0.08, 1.0, 0.1)
+    run_cfg(pkg, orc, cfg, 1500)
