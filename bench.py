@@ -54,7 +54,7 @@ def main():
     dev = torch.device("cuda", local)
 
     cfg = pkg.CONFIGS[args.config]
-    ncpu = len(os.sched_getaffinity(0))
+    ncpu = usable_cores()
     gen_threads = max(1, ncpu // max(1, min(world, 8)))
     t0 = time.time()
     prob = pkg.generate_batch(cfg, args.nprob, pkg.BASE_SEED + rank * args.nprob, nthreads=gen_threads)
@@ -162,6 +162,19 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def usable_cores():
+    """cores this process may actually use: the affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
 
 
 def cpu_baseline(pkg, prob, S0, x0, res, seconds, ncpu):

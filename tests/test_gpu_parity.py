@@ -136,7 +136,8 @@ def test_full_batch_properties_cfg4(pkg, orc):
     x0, S0, st = pkg.phase1_batch(prob)
     z, S, status, detail, stats = pkg.solveQP_batch(prob, S0, x0, want_stats=True)
     assert (status > 0).all() and (detail == 0).all()
-    assert np.abs(z.sum(axis=1) - 1.0).max() < 1e-9 and z.min() >= 0.0 and z.max() <= cfg.ub   # feasibility
+    # feasibility; polishSz! snaps variables within tol = 2^-26 of a bound, so the budget holds to ~N*tol
+    assert np.abs(z.sum(axis=1) - 1.0).max() < 1e-6 and z.min() >= 0.0 and z.max() <= cfg.ub
     sel = np.arange(0, 1024, 16)
     sub = {k: v[sel] for k, v in prob.items()}
     zo, So, sto, _, _ = oracle_batch(orc, sub, S0[sel], x0[sel])
