@@ -61,8 +61,19 @@ __device__ unsigned long long g_phase[1024 * 16];
             (C).ph_cur = (n);                                              \
         }                                                                  \
     } while (0)
+#define SUBPHASE(slot, t0)                                                     \
+    do {                                                                       \
+        if (threadIdx.x == 0) {                                                \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();        \
+            g_phase[(blockIdx.x & 1023) * 16 + (slot)] += t_ - (t0);           \
+            (t0) = t_;                                                         \
+        }                                                                      \
+    } while (0)
+#define SUBPHASE_DECL(t0) unsigned long long t0 = __builtin_amdgcn_s_memtime()
 #else
 #define PHASE(C, n) do { } while (0)
+#define SUBPHASE(slot, t0) do { } while (0)
+#define SUBPHASE_DECL(t0) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------- reductions
@@ -252,6 +263,31 @@ __device__ __forceinline__ void dot2_cols_gather(const double *__restrict__ c0, 
     }
 }
 
+// Per-lane partial dot products of one contiguous global row (a constraint row of Ct) with two LDS vectors.
+template <int VEC>
+__device__ __forceinline__ void row_dot2(const double *__restrict__ row, const double *w1, const double *w2, int N,
+                                         int lane, double &a1, double &a2) {
+    a1 = 0.0;
+    a2 = 0.0;
+    if (VEC >= 2) {
+#pragma unroll 4
+        for (int r = lane * 2; r < N; r += 128) {
+            const double2 v = *reinterpret_cast<const double2 *>(row + r);
+            const double2 x = *reinterpret_cast<const double2 *>(w1 + r);
+            const double2 y = *reinterpret_cast<const double2 *>(w2 + r);
+            a1 = fma(v.y, x.y, fma(v.x, x.x, a1));
+            a2 = fma(v.y, y.y, fma(v.x, y.x, a2));
+        }
+    } else {
+#pragma unroll 4
+        for (int r = lane; r < N; r += 64) {
+            const double v = row[r];
+            a1 = fma(v, w1[r], a1);
+            a2 = fma(v, w2[r], a2);
+        }
+    }
+}
+
 // Partial dot products of four V columns with the LDS vector w: 16 independent
 // 16-byte loads per lane in flight at N = 512 (4 KiB per wave instruction group).
 template <int VEC>
@@ -333,18 +369,24 @@ __device__ __forceinline__ void stream_axpy(const double *__restrict__ V, int N,
             col[c] = V + (size_t)j * N;
             wj[c] = live ? w[j] : 0.0;
         }
+        // all NCOL*NCH loads are issued before the first use: rows beyond N are read from row 0 and dropped
+        double2 v[NCH][NCOL];
 #pragma unroll
         for (int m = 0; m < NCH; ++m) {
             const int r = lane * 2 + 128 * m;
-            if (r < N) {
-                double2 v[NCOL];
+            const int rr = (r < N) ? r : 0;
 #pragma unroll
-                for (int c = 0; c < NCOL; ++c) v[c] = *reinterpret_cast<const double2 *>(col[c] + r);
+            for (int c = 0; c < NCOL; ++c) v[m][c] = *reinterpret_cast<const double2 *>(col[c] + rr);
+        }
 #pragma unroll
-                for (int c = 0; c < NCOL; ++c) {
-                    acc[m].x = fma(v[c].x, wj[c], acc[m].x);
-                    acc[m].y = fma(v[c].y, wj[c], acc[m].y);
-                }
+        for (int m = 0; m < NCH; ++m) {
+            const int r = lane * 2 + 128 * m;
+            const double keep = (r < N) ? 1.0 : 0.0;
+#pragma unroll
+            for (int c = 0; c < NCOL; ++c) {
+                const double wk = wj[c] * keep;
+                acc[m].x = fma(v[m][c].x, wk, acc[m].x);
+                acc[m].y = fma(v[m][c].y, wk, acc[m].y);
             }
         }
     }
@@ -573,7 +615,7 @@ __device__ __forceinline__ int rank_filter_wave(double *X, int W0, int nc, doubl
 // entries a(i,j), rd[j] = 1/d_j, unit-lower L(i,j) = a(i,j)*rd[j]; the border rows of those columns are
 // L^-1 [AE' c], and the trailing (W+1) x (W+1) block is the Schur complement -[AE;c'] V_FF^-1 [AE' c].
 // Returns false when a pivot is not > 0 (where the reference's cholesky throws PosDefException).
-__device__ __forceinline__ bool bordered_ldl(double *fac, double *rd, int jb, int je, int R, const Lds &L) {
+__device__ __forceinline__ bool bordered_ldl1(double *fac, double *rd, int jb, int je, int R, const Lds &L) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool ok = true;
     for (int j = jb; j < je; ++j) {
@@ -586,14 +628,160 @@ __device__ __forceinline__ bool bordered_ldl(double *fac, double *rd, int jb, in
         }
         const double r = 1.0 / d;
         if (threadIdx.x == 0) rd[j] = r;
-        for (int k = j + 1 + wave; k < R; k += NW) {
-            const double f = fac[oj + k - j] * r;
-            const int ok_ = coloff(k, R);
-            for (int i = k + lane; i < R; i += 64) fac[ok_ + i - k] = fma(-f, fac[oj + i - j], fac[ok_ + i - k]);
+        // four columns per wavefront trip: the column-j entry of a row is read once and feeds four
+        // independent read-modify-writes, so their LDS latencies overlap
+        for (int k0 = j + 1 + wave * 4; k0 < R; k0 += NW * 4) {
+            double f[4];
+            int oc[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = k0 + c;
+                const bool live = k < R;
+                f[c] = live ? fac[oj + k - j] * r : 0.0;
+                oc[c] = coloff(live ? k : k0, R) - (live ? k : k0);  // fac[oc + i] is element (i, k)
+            }
+            for (int i = k0 + lane; i < R; i += 64) {
+                const double aij = fac[oj + i - j];
+                double v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = (i >= k0 + c && k0 + c < R) ? fac[oc[c] + i] : 0.0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (i >= k0 + c && k0 + c < R) fac[oc[c] + i] = fma(-f[c], aij, v[c]);
+            }
         }
     }
     __syncthreads();
     return ok;
+}
+
+// Panel version: four columns per step.  Wavefront 0 factors the 4-wide panel (rows j..R-1) in registers --
+// lane = row, the rows of the 4x4 diagonal block are broadcast with v_readlane -- then all wavefronts apply
+// the rank-4 update to the trailing columns.  Two workgroup barriers per FOUR columns instead of one per
+// column.  Needs R - jb <= 256 (four row slots per lane); otherwise the one-column version runs.
+__device__ __forceinline__ double readlane_f64(double v, int srcLane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ bool bordered_ldl(double *fac, double *rd, int jb, int je, int R, const Lds &L) {
+    constexpr int RS = 4;
+    if (R - jb > 64 * RS) return bordered_ldl1(fac, rd, jb, je, R, L);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    SUBPHASE_DECL(tsub);
+    for (int j = jb; j < je; j += 4) {
+        const int nb = (je - j < 4) ? je - j : 4;
+        __syncthreads();
+        SUBPHASE(15, tsub);
+        if (wave == 0) {  // ---- panel factorisation in registers
+            // (loads are unconditional from clamped, always valid addresses; a branch around an LDS load
+            //  would serialise the loads -- each behind its own s_waitcnt)
+            double a[RS][4];
+            int oc[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int jc = j + (c < nb ? c : nb - 1);
+                oc[c] = coloff(jc, R) - jc;
+            }
+#pragma unroll
+            for (int m = 0; m < RS; ++m) {
+                const int i = j + lane + 64 * m;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int jc = j + (c < nb ? c : nb - 1);
+                    const bool live = (c < nb) && (i < R) && (i >= jc);
+                    const double v = fac[oc[c] + (live ? i : jc)];
+                    a[m][c] = live ? v : 0.0;
+                }
+            }
+            bool ok = true;
+            double rc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c < nb) {
+                    const double d = readlane_f64(a[0][c], c);  // a(j+c, j+c)
+                    if (!(d > 0.0)) ok = false;
+                    const double r = 1.0 / d;
+                    rc[c] = r;
+#pragma unroll
+                    for (int c2 = c + 1; c2 < 4; ++c2) {
+                        if (c2 < nb) {
+                            const double l = readlane_f64(a[0][c], c2) * r;  // a(j+c2, j+c) / d
+#pragma unroll
+                            for (int m = 0; m < RS; ++m) {
+                                const int i = j + lane + 64 * m;
+                                const double t = fma(-l, a[m][c], a[m][c2]);
+                                a[m][c2] = (i >= j + c2) ? t : a[m][c2];
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < RS; ++m) {
+                const int i = j + lane + 64 * m;
+#pragma unroll
+                for (int c = 1; c < 4; ++c)
+                    if (c < nb && i < R && i >= j + c) fac[oc[c] + i] = a[m][c];
+            }
+            if (lane == 0) {
+                L.ired[2 * NW + 5] = ok ? 1 : 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < nb) rd[j + c] = rc[c];
+            }
+        }
+        SUBPHASE(13, tsub);
+        __syncthreads();
+        if (!L.ired[2 * NW + 5]) {
+            __syncthreads();
+            return false;
+        }
+        // ---- rank-nb update of the trailing columns (border and Schur block included)
+        int op[4];
+        double rp[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int jc = j + (c < nb ? c : nb - 1);
+            op[c] = coloff(jc, R) - jc;
+            rp[c] = (c < nb) ? rd[jc] : 0.0;
+        }
+        for (int k0 = j + nb + wave * 4; k0 < R; k0 += NW * 4) {
+            double f[4][4];
+            int ok_[4], kq[4];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                kq[q4] = (k0 + q4 < R) ? k0 + q4 : k0;
+                ok_[q4] = coloff(kq[q4], R) - kq[q4];
+            }
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) f[q4][c] = fac[op[c] + kq[q4]];  // 16 independent LDS reads
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) f[q4][c] = (k0 + q4 < R) ? f[q4][c] * rp[c] : 0.0;
+            for (int i = k0 + lane; i < R; i += 64) {
+                double ai[4], v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ai[c] = fac[op[c] + i];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) v[q4] = fac[ok_[q4] + (i >= kq[q4] ? i : kq[q4])];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    double t = v[q4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) t = fma(-f[q4][c], ai[c], t);
+                    if (i >= k0 + q4 && k0 + q4 < R) fac[ok_[q4] + i] = t;
+                }
+            }
+        }
+        SUBPHASE(14, tsub);
+    }
+    __syncthreads();
+    return true;
 }
 
 // Solve the unit upper system L' x = v in place for the n columns j0..j0+n-1 (v[0..n)), one wavefront.
@@ -667,11 +855,24 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             const int r = L.rowsE[w];
             const double *__restrict__ row = Ct + (size_t)r * N;
             double acc = 0.0;
-            for (int i = lane; i < N; i += 64) {
-                const double v = row[i];
-                acc = fma(v, L.zm[i], acc);
-                const int p = L.pos[i];
-                if (p >= 0) X[w + W0 * p] = v;
+            if (VEC >= 2) {
+#pragma unroll 4
+                for (int i = lane * 2; i < N; i += 128) {
+                    const double2 v = *reinterpret_cast<const double2 *>(row + i);
+                    const double2 zz = *reinterpret_cast<const double2 *>(L.zm + i);
+                    const int p0 = L.pos[i], p1 = L.pos[i + 1];
+                    acc = fma(v.y, zz.y, fma(v.x, zz.x, acc));
+                    if (p0 >= 0) X[w + W0 * p0] = v.x;
+                    if (p1 >= 0) X[w + W0 * p1] = v.y;
+                }
+            } else {
+#pragma unroll 4
+                for (int i = lane; i < N; i += 64) {
+                    const double v = row[i];
+                    acc = fma(v, L.zm[i], acc);
+                    const int p = L.pos[i];
+                    if (p >= 0) X[w + W0 * p] = v;
+                }
             }
             acc = wave_sum(acc);
             if (lane == 0) {
@@ -832,12 +1033,8 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         for (int o = wave; o < JO; o += NW) {
             const int j = L.iO[o];
             const double *__restrict__ row = Ct + (size_t)(M + j) * N;
-            double az = 0.0, ap = 0.0;
-            for (int i = lane; i < N; i += 64) {
-                const double v = row[i];
-                az = fma(v, L.z[i], az);
-                ap = fma(v, L.zm[i], ap);
-            }
+            double az, ap;
+            row_dot2<VEC>(row, L.z, L.zm, N, lane, az, ap);
             az = wave_sum(az);
             ap = wave_sum(ap);
             if (lane == 0) L.lin[o] = (ap > tol) ? (rhs[M + j] - az) / ap : inf;
@@ -923,6 +1120,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         if (L.pos[i] >= 0) continue;
         double gmm = L.gam[i] + q[i];
         double s3 = 0.0;
+#pragma unroll 4
         for (int w = 0; w < W; ++w) s3 = fma(Ct[(size_t)L.rowsE[L.ra[w]] * N + i], L.aL[w], s3);
         gmm += s3;
         const int s = L.S[i];
@@ -1028,8 +1226,8 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     __syncthreads();
     for (int j = wave; j < J; j += NW) {
         const double *__restrict__ row = Ct + (size_t)(M + j) * N;
-        double az = 0.0;
-        for (int i = lane; i < N; i += 64) az = fma(row[i], L.z[i], az);
+        double az, unused;
+        row_dot2<VEC>(row, L.z, L.z, N, lane, az, unused);
         az = wave_sum(az);
         if (lane == 0) L.S[N + j] = (fabs(rhs[M + j] - az) < tol) ? SSQP_EO : SSQP_OE;
     }
@@ -1039,7 +1237,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
 }
 
 template <int VEC>
-__device__ void solve_one(const SolveParams &P, int prob, const Lds &L, double *garena) {
+__device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const Lds &L, double *garena) {
     const int N = P.N, M = P.M, J = P.J;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     ProbCtx C;

@@ -21,7 +21,7 @@ lib.ssqp_debug_phases(out, 1)
 db.solve(); res = db.results()
 lib.ssqp_debug_phases(out, 1)
 names = ["compaction+lists", "E-row sweep", "rank filter", "pass1 V[:,F]+gather", "bordered LDL", "Schur+lambda",
-         "vk+back-subst", "alpha/p/norm", "aStep", "pass2 V[:,B] gamma", "KKTchk", "load/polish/store", "freeK", "tail"]
+         "vk+back-subst", "alpha/p/norm", "aStep", "pass2 V[:,B] gamma", "KKTchk", "load/polish/store", "freeK", "ldl:panel(w0)", "ldl:update", "ldl:barrier-wait"]
 tot = sum(out)
 iters = int(res["status"].sum())
 print("config", name, "nprob", nprob, "total iterations", iters, "kernel ms", db.ctx.last_kernel_ms())
