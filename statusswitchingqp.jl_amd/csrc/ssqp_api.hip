@@ -195,6 +195,9 @@ int ssqp_solve_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const 
     {
         const char *e = getenv("SSQP_DENSE_GAMMA");
         P.denseGamma = (e && atoi(e) != 0) ? 1 : 0;
+        const char *f = getenv("SSQP_INCREMENTAL");
+        P.incremental = (f && atoi(f) == 0) ? 0 : 1;
+        if (P.denseGamma) P.incremental = 0;  // the dense-formulation run is the from-scratch, reference-shaped pass
     }
     P.arenaCap = ((ldsPerWG - fixed - 64) / 16) * 2;
     if (P.arenaCap < 0) P.arenaCap = 0;

@@ -40,13 +40,14 @@ struct SolveParams {
     size_t gscratchStride;   // doubles per workgroup
     int arenaCap;            // doubles in the LDS arena
     int denseGamma;          // 1: the gamma pass reads every column of V (dense formulation, for roofline runs)
+    int incremental;         // 1: keep the LDL' factor across passes (append/delete) instead of refactoring
 };
 
 // Offsets of the LDS carve-up.  Double-typed regions first (offsets in
 // doubles), then the integer regions (offsets in bytes).
 struct LdsLayout {
     int z, zm, gam, arena, bE, aL, tv, dcol, lin, red;  // in doubles
-    int S_bytes, ired_bytes, pos_bytes, idx_bytes, perm_bytes, rowsE_bytes, ra_bytes, iO_bytes;
+    int S_bytes, ired_bytes, pos_bytes, idx_bytes, perm_bytes, rowsE_bytes, ra_bytes, iO_bytes, fpos_bytes, ordl_bytes;
     int total_bytes;
 };
 
@@ -59,7 +60,7 @@ __host__ __device__ inline int lds_fixed_bytes(int N, int M, int J) {
     int bytes = dbl * 8;
     bytes += align_up(4 * (N + J), 8);           // S
     bytes += align_up(4 * (2 * NW + 16), 8);     // ired
-    bytes += 3 * align_up(2 * (N + 2), 8);       // pos, idx, perm
+    bytes += 5 * align_up(2 * (N + 2), 8);       // pos, idx, perm, fpos, ordl
     bytes += 3 * align_up(2 * (M + J + 2), 8);   // rowsE, ra, iO
     return bytes;
 }
@@ -87,6 +88,8 @@ __host__ __device__ inline LdsLayout lds_layout(int N, int M, int J, int arenaCa
     l.rowsE_bytes = b; b += align_up(2 * (M + J + 2), 8);
     l.ra_bytes = b; b += align_up(2 * (M + J + 2), 8);
     l.iO_bytes = b; b += align_up(2 * (M + J + 2), 8);
+    l.fpos_bytes = b; b += align_up(2 * (N + 2), 8);
+    l.ordl_bytes = b; b += align_up(2 * (N + 2), 8);
     l.total_bytes = b;
     return l;
 }

@@ -42,6 +42,14 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
+// 1/d by v_rcp_f64 and two Newton steps (about 1 ulp; the IEEE division sequence is ~3x longer and sits on
+// the critical path of every elimination step)
+__device__ __forceinline__ double fast_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
 // x - d*y and x/d with the reference's two roundings (no FMA contraction)
 __device__ __forceinline__ double sub_mul_nc(double x, double d, double y) {
 #pragma clang fp contract(off)
@@ -150,7 +158,7 @@ struct Lds {
     double *red;                         // 2*NW
     int32_t *S;
     int *ired;                           // 2*NW + 8
-    int16_t *pos, *idx, *perm, *rowsE, *ra, *iO;
+    int16_t *pos, *idx, *perm, *rowsE, *ra, *iO, *fpos, *ordl;
 };
 
 __device__ __forceinline__ double block_max(double v, const Lds &L) {
@@ -626,7 +634,7 @@ __device__ __forceinline__ bool bordered_ldl1(double *fac, double *rd, int jb, i
             ok = false;
             break;
         }
-        const double r = 1.0 / d;
+        const double r = fast_rcp(d);
         if (threadIdx.x == 0) rd[j] = r;
         // four columns per wavefront trip: the column-j entry of a row is read once and feeds four
         // independent read-modify-writes, so their LDS latencies overlap
@@ -679,6 +687,7 @@ __device__ __forceinline__ bool bordered_ldl(double *fac, double *rd, int jb, in
             //  would serialise the loads -- each behind its own s_waitcnt)
             double a[RS][4];
             int oc[4];
+            const int nsl = (R - j + 63) >> 6;  // row slots in use (uniform)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int jc = j + (c < nb ? c : nb - 1);
@@ -687,6 +696,9 @@ __device__ __forceinline__ bool bordered_ldl(double *fac, double *rd, int jb, in
 #pragma unroll
             for (int m = 0; m < RS; ++m) {
                 const int i = j + lane + 64 * m;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[m][c] = 0.0;
+                if (m < nsl)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int jc = j + (c < nb ? c : nb - 1);
@@ -702,7 +714,7 @@ __device__ __forceinline__ bool bordered_ldl(double *fac, double *rd, int jb, in
                 if (c < nb) {
                     const double d = readlane_f64(a[0][c], c);  // a(j+c, j+c)
                     if (!(d > 0.0)) ok = false;
-                    const double r = 1.0 / d;
+                    const double r = fast_rcp(d);
                     rc[c] = r;
 #pragma unroll
                     for (int c2 = c + 1; c2 < 4; ++c2) {
@@ -710,9 +722,11 @@ __device__ __forceinline__ bool bordered_ldl(double *fac, double *rd, int jb, in
                             const double l = readlane_f64(a[0][c], c2) * r;  // a(j+c2, j+c) / d
 #pragma unroll
                             for (int m = 0; m < RS; ++m) {
-                                const int i = j + lane + 64 * m;
-                                const double t = fma(-l, a[m][c], a[m][c2]);
-                                a[m][c2] = (i >= j + c2) ? t : a[m][c2];
+                                if (m < nsl) {
+                                    const int i = j + lane + 64 * m;
+                                    const double t = fma(-l, a[m][c], a[m][c2]);
+                                    a[m][c2] = (i >= j + c2) ? t : a[m][c2];
+                                }
                             }
                         }
                     }
@@ -798,6 +812,216 @@ __device__ __forceinline__ void back_substitute(const double *fac, const double 
     }
 }
 
+
+// =====================================================================================================
+// Incremental KKT engine.  The reference refactors V[F,F] from scratch on every pass (SSQP.jl:322) although F
+// changes by one index at a time.  Here the unit-lower LDL' factor of V[F,F] is
+// KEPT in LDS across passes, with the free variables in insertion order:
+//   release of a variable  -> append one row  (one forward substitution)
+//   blocked variable(s)    -> delete a row/column (rank-1 update of the trailing block + compaction)
+// and each pass only does: forward substitution of the border [AE' c], the (W+1)^2 Schur block, lambda, one
+// back substitution.  Same KKT system as the from-scratch path; the pivot order differs, results agree to
+// rounding.  Column c of the factor lives at cofs(c) = c*RC - c(c-1)/2 with rows c..RC-1 (fixed capacity RC,
+// so appending a row moves nothing): slot 0 is d_c, the rest L(r,c).  Rows are spread over lanes: row r is
+// lane r&63 of register slot r>>6 (two slots: K <= 128).
+// =====================================================================================================
+constexpr int INC_RBM = 8;    // border right-hand sides the engine carries (W + 1 <= 8)
+constexpr int INC_KMAX = 128; // two register slots of 64 rows
+
+struct Inc {
+    double *fcol, *rdv, *Y;  // factor, reciprocal pivots, border right-hand sides (RC per column)
+    int16_t *ord, *fpos;     // row -> variable, variable -> row (or -1)
+    int RC;
+};
+__device__ __forceinline__ int cofs(int c, int RC) { return c * RC - ((c * (c - 1)) >> 1); }
+
+// value of row r (uniform) from the two register slots
+__device__ __forceinline__ double row_bcast(double s0, double s1, int r) {
+    return (r < 64) ? readlane_f64(s0, r) : readlane_f64(s1, r - 64);
+}
+
+// Append variable j as row K (wavefront 0 only).  Returns false when the new pivot is not > 0.
+__device__ __forceinline__ bool inc_append(const Inc &I, int K, int j, const double *__restrict__ V, int N) {
+    const int lane = threadIdx.x & 63;
+    const int RC = I.RC;
+    const double *__restrict__ col = V + (size_t)j * N;
+    const int r0 = lane, r1 = lane + 64;
+    const double vjj = col[j];
+    double y0 = (r0 < K) ? col[I.ord[r0 < K ? r0 : 0]] : 0.0;
+    double y1 = (r1 < K) ? col[I.ord[r1 < K ? r1 : 0]] : 0.0;
+#pragma unroll 4
+    for (int c = 0; c < K; ++c) {
+        const int oc = cofs(c, RC) - c;
+        const double l0 = I.fcol[oc + ((r0 > c && r0 < K) ? r0 : c)];
+        const double l1 = I.fcol[oc + ((r1 > c && r1 < K) ? r1 : c)];
+        const double yc = row_bcast(y0, y1, c);
+        y0 = (r0 > c && r0 < K) ? fma(-l0, yc, y0) : y0;
+        y1 = (r1 > c && r1 < K) ? fma(-l1, yc, y1) : y1;
+    }
+    const double t0 = (r0 < K) ? y0 * I.rdv[r0 < K ? r0 : 0] : 0.0;
+    const double t1 = (r1 < K) ? y1 * I.rdv[r1 < K ? r1 : 0] : 0.0;
+    const double dnew = vjj - wave_sum(fma(y0, t0, y1 * t1));
+    if (r0 < K) I.fcol[cofs(r0, RC) + K - r0] = t0;
+    if (r1 < K) I.fcol[cofs(r1, RC) + K - r1] = t1;
+    if (lane == 0) {
+        I.fcol[cofs(K, RC)] = dnew;
+        I.rdv[K] = fast_rcp(dnew);
+        I.ord[K] = (int16_t)j;
+        I.fpos[j] = (int16_t)K;
+    }
+    wave_sync();
+    return dnew > 0.0;
+}
+
+// Rank-1 part of deleting row p: L33 D3 L33' += d_p l l'  (wavefront 0 only).
+__device__ __forceinline__ void inc_delete_update(const Inc &I, int K, int p) {
+    const int lane = threadIdx.x & 63;
+    const int RC = I.RC;
+    const int r0 = lane, r1 = lane + 64;
+    double d0 = (r0 < K) ? I.fcol[cofs(r0 < K ? r0 : 0, RC)] : 1.0;
+    double d1 = (r1 < K) ? I.fcol[cofs(r1 < K ? r1 : 0, RC)] : 1.0;
+    const int op = cofs(p, RC) - p;
+    double w0 = (r0 > p && r0 < K) ? I.fcol[op + r0] : 0.0;
+    double w1 = (r1 > p && r1 < K) ? I.fcol[op + r1] : 0.0;
+    double alpha = row_bcast(d0, d1, p);
+    for (int k = p + 1; k < K; ++k) {
+        const int ok = cofs(k, RC) - k;
+        double l0 = I.fcol[ok + ((r0 > k && r0 < K) ? r0 : k)];
+        double l1 = I.fcol[ok + ((r1 > k && r1 < K) ? r1 : k)];
+        const double pk = row_bcast(w0, w1, k);
+        const double dk = row_bcast(d0, d1, k);
+        const double dn = fma(alpha * pk, pk, dk);
+        const double rdn = fast_rcp(dn);
+        const double beta = pk * alpha * rdn;
+        alpha = alpha * dk * rdn;
+        if (r0 == k) d0 = dn;
+        if (r1 == k) d1 = dn;
+        if (r0 > k && r0 < K) {
+            w0 = fma(-pk, l0, w0);
+            l0 = fma(beta, w0, l0);
+            I.fcol[ok + r0] = l0;
+        }
+        if (r1 > k && r1 < K) {
+            w1 = fma(-pk, l1, w1);
+            l1 = fma(beta, w1, l1);
+            I.fcol[ok + r1] = l1;
+        }
+    }
+    if (r0 > p && r0 < K) {
+        I.fcol[cofs(r0, RC)] = d0;
+        I.rdv[r0] = fast_rcp(d0);
+    }
+    if (r1 > p && r1 < K) {
+        I.fcol[cofs(r1, RC)] = d1;
+        I.rdv[r1] = fast_rcp(d1);
+    }
+    wave_sync();
+}
+
+// Physically remove row/column p (all wavefronts; contains workgroup barriers, call uniformly).
+__device__ __forceinline__ void inc_delete_compact(const Inc &I, int K, int p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int RC = I.RC;
+    const int r0 = lane, r1 = lane + 64;
+    // (A) columns c < p lose row p: rows r > p move up by one inside the column
+    for (int c = wave; c < p; c += NW) {
+        const int oc = cofs(c, RC) - c;
+        const double a0 = (r0 > p && r0 < K) ? I.fcol[oc + r0] : 0.0;
+        const double a1 = (r1 > p && r1 < K) ? I.fcol[oc + r1] : 0.0;
+        wave_sync();
+        if (r0 > p && r0 < K) I.fcol[oc + r0 - 1] = a0;
+        if (r1 > p && r1 < K) I.fcol[oc + r1 - 1] = a1;
+    }
+    // bookkeeping of rows > p (one wavefront: read everything, then write)
+    if (wave == NW - 1) {
+        const double q0 = (r0 > p && r0 < K) ? I.rdv[r0] : 0.0, q1 = (r1 > p && r1 < K) ? I.rdv[r1] : 0.0;
+        const int v0 = (r0 > p && r0 < K) ? I.ord[r0] : 0, v1 = (r1 > p && r1 < K) ? I.ord[r1] : 0;
+        const int vdel = I.ord[p];
+        wave_sync();
+        if (lane == 0) I.fpos[vdel] = -1;
+        if (r0 > p && r0 < K) {
+            I.rdv[r0 - 1] = q0;
+            I.ord[r0 - 1] = (int16_t)v0;
+            I.fpos[v0] = (int16_t)(r0 - 1);
+        }
+        if (r1 > p && r1 < K) {
+            I.rdv[r1 - 1] = q1;
+            I.ord[r1 - 1] = (int16_t)v1;
+            I.fpos[v1] = (int16_t)(r1 - 1);
+        }
+    }
+    // (B) columns c > p become columns c-1 (rows shift up too): rounds of NW columns, read - barrier - write
+    for (int c0 = p + 1; c0 < K; c0 += NW) {
+        const int c = c0 + wave;
+        const bool live = c < K;
+        const int oc = cofs(live ? c : p + 1, RC) - (live ? c : p + 1);
+        const double a0 = (live && r0 >= c && r0 < K) ? I.fcol[oc + r0] : 0.0;
+        const double a1 = (live && r1 >= c && r1 < K) ? I.fcol[oc + r1] : 0.0;
+        __syncthreads();
+        if (live) {
+            const int on = cofs(c - 1, RC) - (c - 1);
+            if (r0 >= c && r0 < K) I.fcol[on + r0 - 1] = a0;
+            if (r1 >= c && r1 < K) I.fcol[on + r1 - 1] = a1;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+}
+
+// Forward substitution L y = b for the border right-hand sides, in place in I.Y.  Right-hand side k of the
+// list (physical column phys[k] of Y) is taken by wavefront k & (NW-1): no exchange between wavefronts.
+__device__ __forceinline__ void inc_forward_border(const Inc &I, int K, int nrhs, const int16_t *phys) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int RC = I.RC;
+    const int r0 = lane, r1 = lane + 64;
+    const int b0 = wave, b1 = wave + NW;
+    if (b0 >= nrhs) return;
+    const bool two = b1 < nrhs;
+    double *Y0 = I.Y + (size_t)phys[b0] * RC;
+    double *Y1 = I.Y + (size_t)phys[two ? b1 : b0] * RC;
+    double y00 = (r0 < K) ? Y0[r0] : 0.0, y01 = (r1 < K) ? Y0[r1] : 0.0;
+    double y10 = (r0 < K) ? Y1[r0] : 0.0, y11 = (r1 < K) ? Y1[r1] : 0.0;
+#pragma unroll 4
+    for (int c = 0; c < K; ++c) {
+        const int oc = cofs(c, RC) - c;
+        const double l0 = I.fcol[oc + ((r0 > c && r0 < K) ? r0 : c)];
+        const double l1 = I.fcol[oc + ((r1 > c && r1 < K) ? r1 : c)];
+        const double ya = row_bcast(y00, y01, c);
+        const double yb = row_bcast(y10, y11, c);
+        if (r0 > c && r0 < K) {
+            y00 = fma(-l0, ya, y00);
+            y10 = fma(-l0, yb, y10);
+        }
+        if (r1 > c && r1 < K) {
+            y01 = fma(-l1, ya, y01);
+            y11 = fma(-l1, yb, y11);
+        }
+    }
+    if (r0 < K) Y0[r0] = y00;
+    if (r1 < K) Y0[r1] = y01;
+    if (two) {
+        if (r0 < K) Y1[r0] = y10;
+        if (r1 < K) Y1[r1] = y11;
+    }
+}
+
+// Back substitution L' x = v (unit upper), v in two register slots, wavefront 0 only.
+__device__ __forceinline__ void inc_backward(const Inc &I, int K, double &v0, double &v1) {
+    const int lane = threadIdx.x & 63;
+    const int RC = I.RC;
+    const int c0 = lane, c1 = lane + 64;
+    const int o0 = cofs(c0 < K ? c0 : 0, RC) - (c0 < K ? c0 : 0);
+    const int o1 = cofs(c1 < K ? c1 : 0, RC) - (c1 < K ? c1 : 0);
+#pragma unroll 4
+    for (int r = K - 1; r > 0; --r) {
+        const double l0 = I.fcol[o0 + (c0 < r ? r : (c0 < K ? c0 : 0))];  // L(r, c0): row r of column c0
+        const double l1 = I.fcol[o1 + (c1 < r ? r : (c1 < K ? c1 : 0))];
+        const double xr = row_bcast(v0, v1, r);
+        if (c0 < r) v0 = fma(-l0, xr, v0);
+        if (c1 < r) v1 = fma(-l1, xr, v1);
+    }
+}
+
 // ------------------------------------------------------------------ the loop
 struct ProbCtx {
     int N, M, J, MJ;
@@ -818,6 +1042,10 @@ struct ProbCtx {
     int32_t det;
     int64_t sBytes, sRead, sFlops, sK3;
     int maxK, pathBits;
+    // incremental engine state
+    int Kfac;     // rows currently in the kept factor (0: empty / invalid)
+    int RC;       // factor capacity (0: engine disabled for this problem shape)
+    int yOff, rdvOff, facOff;  // arena offsets (doubles)
 #ifdef SSQP_PHASE_PROFILE
     unsigned long long ph_last;
     int ph_cur;
@@ -846,6 +1074,98 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     constexpr int MPT = (VEC == 2) ? 2 : ((VEC == 3) ? 4 : MAXPT);
     const int64_t iter = C.iter;
     ssqp_trace *trace = (C.trace && iter <= C.ntrace) ? C.trace + (iter - 1) : nullptr;
+
+    // ---- incremental engine: bring the kept factor in line with the current free set ----
+    bool useInc = false;
+    if (INLDS) useInc = (C.RC > 0) && (K <= C.RC) && (W0 + 1 <= INC_RBM);
+    Inc I;
+    I.fcol = ar + C.facOff;
+    I.rdv = ar + C.rdvOff;
+    I.Y = ar + C.yOff;
+    I.ord = L.ordl;
+    I.fpos = L.fpos;
+    I.RC = C.RC;
+    if (useInc) {
+        PHASE(C, 13);
+        int Kf = C.Kfac;
+        if (Kf < 0) {  // the factor was overwritten by a from-scratch pass: start over
+            for (int i = tid; i < N; i += NT) L.fpos[i] = -1;
+            Kf = 0;
+            __syncthreads();
+        }
+        // deletions: rows whose variable is no longer IN (highest row first: cheapest, indices below stay)
+        {
+            const int r = tid;  // rows 0..127 are covered by wavefronts 0 and 1
+            const bool dead = (r < Kf) && (L.S[I.ord[r < Kf ? r : 0]] != SSQP_IN);
+            const unsigned long long m = __ballot(dead);
+            if (lane == 0 && wave < 2) {
+                L.ired[2 * NW + 6 + 2 * wave] = (int)(m & 0xffffffffull);
+                L.ired[2 * NW + 7 + 2 * wave] = (int)(m >> 32);
+            }
+        }
+        __syncthreads();
+        unsigned long long dm0 = ((unsigned long long)(unsigned)L.ired[2 * NW + 7] << 32) | (unsigned)L.ired[2 * NW + 6];
+        unsigned long long dm1 = ((unsigned long long)(unsigned)L.ired[2 * NW + 9] << 32) | (unsigned)L.ired[2 * NW + 8];
+        while (dm0 | dm1) {
+            int pdel;
+            if (dm1) {
+                pdel = 127 - __clzll(dm1);
+                dm1 &= ~(1ull << (pdel - 64));
+            } else {
+                pdel = 63 - __clzll(dm0);
+                dm0 &= ~(1ull << pdel);
+            }
+            if (wave == 0) inc_delete_update(I, Kf, pdel);
+            __syncthreads();
+            inc_delete_compact(I, Kf, pdel);
+            Kf -= 1;
+        }
+        // appends: IN variables that have no row yet, by increasing index
+        int nA = 0;
+        {
+            const int lane_ = lane, wave_ = wave;
+            int base = 0;
+            for (int c0 = 0; c0 < N; c0 += NT) {
+                const int i = c0 + tid;
+                const bool f = (i < N) && (L.S[i] == SSQP_IN) && (L.fpos[i] < 0);
+                const unsigned long long m = __ballot(f);
+                const int lp = __popcll(m & ((1ull << lane_) - 1ull));
+                if (lane_ == 0) L.ired[wave_] = __popcll(m);
+                __syncthreads();
+                int wb = 0, tot = 0;
+#pragma unroll
+                for (int wv = 0; wv < NW; ++wv) {
+                    const int cnt = L.ired[wv];
+                    if (wv < wave_) wb += cnt;
+                    tot += cnt;
+                }
+                if (f) L.perm[base + wb + lp] = (int16_t)i;
+                base += tot;
+                __syncthreads();
+            }
+            nA = base;
+        }
+        bool okA = true;
+        for (int a = 0; a < nA; ++a) {
+            if (wave == 0) {
+                const bool ok1 = inc_append(I, Kf, L.perm[a], V, N);
+                if (lane == 0) L.ired[2 * NW + 5] = ok1 ? 1 : 0;
+            }
+            __syncthreads();
+            if (!L.ired[2 * NW + 5]) {
+                okA = false;
+                break;
+            }
+            Kf += 1;
+        }
+        C.Kfac = Kf;
+        C.sRead += 64ll * nA * K;  // the K scattered entries of each appended column (one 64-byte sector each)
+        if (!okA) {  // cholesky(V[F,F]) of the reference would throw here
+            C.ret = -1;
+            C.det = SSQP_DETAIL_POSDEF_V;
+            return ACT_BREAK;
+        }
+    }
 
     // ---- E-row sweep: bE and X = [AE bE]   (SSQP.jl:290-295) ----
     PHASE(C, 1);
@@ -883,6 +1203,13 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         }
     }
     __syncthreads();
+    if (useInc) {  // border right-hand sides AE' in factor order (the rank filter is about to destroy X)
+        for (int e = tid; e < W0 * K; e += NT) {
+            const int w = e / K, r = e - w * K;
+            I.Y[(size_t)w * I.RC + r] = ar[w + W0 * (int)L.pos[I.ord[r]]];
+        }
+        __syncthreads();
+    }
     // ---- rank filter  (SSQP.jl:310-319) ----
     PHASE(C, 2);
     int W = W0;
@@ -908,10 +1235,113 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     }
     __syncthreads();
 
+    double *fac = ar;  // (from-scratch path: packed factor; least-squares scratch of KKTchk! in both paths)
+    if (useInc) {
+        // =========================== incremental engine ===========================
+        PHASE(C, 3);
+        C.pathBits |= 4;
+        // c = V[B,F]'zB + q[F]: hB = V[:, nz(zB)] zB in AXPY form (only the bound variables that are not at 0)
+        {
+            const int ncols = stream_matvec<VEC>(V, N, L.zm, C.dense, ar, L.gam, L);
+            C.sRead += 8ll * N * ncols - 8ll * N * K;  // (the K term is added by the common accounting below)
+        }
+        __syncthreads();
+        for (int r = tid; r < K; r += NT) {
+            const int i = I.ord[r];
+            I.Y[(size_t)W0 * I.RC + r] = L.gam[i] + q[i];
+        }
+        if (tid <= W) L.perm[tid] = (tid < W) ? L.ra[tid] : (int16_t)W0;  // physical right-hand sides
+        __syncthreads();
+        PHASE(C, 4);
+        inc_forward_border(I, K, W + 1, L.perm);
+        __syncthreads();
+        PHASE(C, 5);
+        // Schur block: H = AE V^-1 AE' (W x W, lower) into the scratch arena, t = AE V^-1 c into tv
+        double *H = ar;
+        for (int e = wave; e < W * (W + 1) / 2 + W; e += NW) {
+            int a, b;
+            if (e < W) {
+                a = W;
+                b = e;
+            } else {
+                int f = e - W, col = 0;
+                while (f >= W - col) {
+                    f -= W - col;
+                    ++col;
+                }
+                a = col + f;
+                b = col;
+            }
+            const double *Ya = I.Y + (size_t)L.perm[a] * I.RC, *Yb = I.Y + (size_t)L.perm[b] * I.RC;
+            double acc = 0.0;
+            for (int r = lane; r < K; r += 64) acc = fma(Ya[r] * I.rdv[r], Yb[r], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) {
+                if (e < W) L.tv[b] = acc;
+                else H[a + W * b] = acc;
+            }
+        }
+        __syncthreads();
+        if (wave == 0 && lane == 0) {  // lambda: H lam = bE + t, alphaL = -lam; W <= 7
+            bool okH = true;
+            for (int c = 0; c < W && okH; ++c) {
+                const double dcc = H[c + W * c];
+                if (!(dcc > 0.0)) {
+                    okH = false;
+                    break;
+                }
+                const double rc = 1.0 / dcc;
+                for (int k2 = c + 1; k2 < W; ++k2) {
+                    const double f = H[k2 + W * c] * rc;
+                    for (int i2 = k2; i2 < W; ++i2) H[i2 + W * k2] = fma(-f, H[i2 + W * c], H[i2 + W * k2]);
+                }
+            }
+            L.ired[2 * NW + 2] = okH ? 1 : 0;
+            if (okH) {
+                for (int w = 0; w < W; ++w) L.aL[w] = L.bE[w] + L.tv[w];
+                for (int c = 0; c < W; ++c) {
+                    const double xc = L.aL[c], rc = 1.0 / H[c + W * c];
+                    for (int i2 = c + 1; i2 < W; ++i2) L.aL[i2] = fma(-H[i2 + W * c] * rc, xc, L.aL[i2]);
+                }
+                for (int c = 0; c < W; ++c) L.aL[c] = L.aL[c] / H[c + W * c];
+                for (int c = W - 1; c >= 0; --c) {
+                    double xc = L.aL[c];
+                    const double rc = 1.0 / H[c + W * c];
+                    for (int i2 = c + 1; i2 < W; ++i2) xc = fma(-H[i2 + W * c] * rc, L.aL[i2], xc);
+                    L.aL[c] = xc;
+                }
+                for (int w = 0; w < W; ++w) L.aL[w] = -L.aL[w];
+            }
+        }
+        __syncthreads();
+        if (!L.ired[2 * NW + 2]) {
+            C.ret = -1;
+            C.det = SSQP_DETAIL_POSDEF_C;
+            return ACT_BREAK;
+        }
+        PHASE(C, 6);
+        if (wave == 0) {  // v = D^-1 (Y_A alphaL + y_c); alpha = -L'^-1 v
+            const int r0 = lane, r1 = lane + 64;
+            const double *Yc = I.Y + (size_t)W0 * I.RC;
+            double v0 = (r0 < K) ? Yc[r0] : 0.0, v1 = (r1 < K) ? Yc[r1] : 0.0;
+            for (int w = 0; w < W; ++w) {
+                const double *Yw = I.Y + (size_t)L.perm[w] * I.RC;
+                const double aw = L.aL[w];
+                if (r0 < K) v0 = fma(Yw[r0], aw, v0);
+                if (r1 < K) v1 = fma(Yw[r1], aw, v1);
+            }
+            v0 *= (r0 < K) ? I.rdv[r0] : 0.0;
+            v1 *= (r1 < K) ? I.rdv[r1] : 0.0;
+            inc_backward(I, K, v0, v1);
+            if (r0 < K) L.gam[I.ord[r0]] = -v0;
+            if (r1 < K) L.gam[I.ord[r1]] = -v1;
+        }
+        __syncthreads();
+    } else {
+        if (INLDS) C.Kfac = -1;  // the from-scratch path overwrites the arena: the kept factor is gone
     // ---- factor assembly: pass 1 over V[:,F] + border rows ----
     PHASE(C, 3);
     const int Rr = K + W + 1;
-    double *fac = ar;
     double *rd = ar + coloff(Rr, Rr);  // Rr reciprocal pivots behind the packed R x R triangle
     for (int t = wave * 2; t < K; t += NW * 2) {
         const bool two = (t + 1 < K);
@@ -990,15 +1420,30 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     __syncthreads();
     if (wave == 0) back_substitute(fac, rd, vk, 0, K, Rr);
     __syncthreads();
+    {  // alpha = -x, scattered to the variables' own slots of gam
+        double t[MPT];
+#pragma unroll
+        for (int m = 0; m < MPT; ++m) {
+            const int k = tid + m * NT;
+            t[m] = (k < K) ? -vk[k] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MPT; ++m) {
+            const int k = tid + m * NT;
+            if (k < K) L.gam[L.idx[k]] = t[m];
+        }
+        __syncthreads();
+    }
+    }
     // ---- alpha (scattered into gam), p (scattered into zm) ----
     PHASE(C, 7);
     double areg[MPT];
 #pragma unroll
     for (int m = 0; m < MPT; ++m) {
         const int k = tid + m * NT;
-        areg[m] = (k < K) ? -vk[k] : 0.0;
+        areg[m] = (k < K) ? L.gam[L.idx[k < K ? k : 0]] : 0.0;
     }
-    __syncthreads();
     double pa = 0.0;
     int pnan = 0;
     for (int i = tid; i < N; i += NT)
@@ -1009,7 +1454,6 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         if (k < K) {
             const int i = L.idx[k];
             const double p = areg[m] - L.z[i];
-            L.gam[i] = areg[m];
             L.zm[i] = p;
             if (p != p) pnan = 1;
             pa = fmax(pa, fabs(p));
@@ -1265,6 +1709,27 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
 
     for (int i = tid; i < N; i += NT) L.z[i] = P.x0[(size_t)prob * N + i];
     for (int i = tid; i < N + J; i += NT) L.S[i] = Sg[i];
+    for (int i = tid; i < N; i += NT) L.fpos[i] = -1;
+    // incremental engine: arena = [scratch (X / AXPY staging / H) | Y | 1/d | factor], capacity RC rows
+    C.Kfac = 0;
+    C.RC = 0;
+    C.yOff = C.rdvOff = C.facOff = 0;
+    if (P.incremental) {
+        int rc = INC_KMAX;
+        for (; rc >= 16; rc -= 2) {
+            long scr = (long)NW * N + 64;
+            const long x = (long)P.MJ * (rc + 2) + 64;
+            if (x > scr) scr = x;
+            const long need = scr + (long)INC_RBM * rc + rc + (long)rc * (rc + 1) / 2 + 8;
+            if (need <= P.arenaCap) {
+                C.RC = rc;
+                C.yOff = (int)scr;
+                C.rdvOff = C.yOff + INC_RBM * rc;
+                C.facOff = C.rdvOff + rc;
+                break;
+            }
+        }
+    }
     __syncthreads();
 
     for (;;) {
@@ -1419,6 +1884,8 @@ __global__ __launch_bounds__(NT, WPS) void ssqp_solve_kernel(SolveParams P) {
         L.rowsE = reinterpret_cast<int16_t *>(smem + lay.rowsE_bytes);
         L.ra = reinterpret_cast<int16_t *>(smem + lay.ra_bytes);
         L.iO = reinterpret_cast<int16_t *>(smem + lay.iO_bytes);
+        L.fpos = reinterpret_cast<int16_t *>(smem + lay.fpos_bytes);
+        L.ordl = reinterpret_cast<int16_t *>(smem + lay.ordl_bytes);
     }
     double *garena = P.gscratch + (size_t)blockIdx.x * P.gscratchStride;
     for (;;) {

@@ -35,7 +35,7 @@ def test_reference_kat_3x3(pkg):
 
 def test_cfg1_n50(pkg, orc):
     rel, stats = run_cfg(pkg, orc, pkg.CONFIGS["cfg1"], 16)
-    assert (stats["path"] == 1).all()
+    assert ((stats["path"] & 2) == 0).all()      # never left the LDS arena (bit 2 = incremental engine used)
 
 
 def test_small_with_inequalities(pkg, orc):
@@ -55,7 +55,7 @@ def test_multi_equalities(pkg, orc):
 
 def test_cfg2_n512(pkg, orc):
     rel, stats = run_cfg(pkg, orc, pkg.CONFIGS["cfg2"], 8)
-    assert (stats["path"] == 1).all()
+    assert ((stats["path"] & 2) == 0).all()      # never left the LDS arena (bit 2 = incremental engine used)
 
 
 def test_cfg3_n256_large_k_global_arena(pkg, orc):
