@@ -167,6 +167,10 @@ int ssqp_generate_problem(const ssqp_gen_cfg *cfg, uint64_t seed, double *V, dou
 int ssqp_generate_batch(const ssqp_gen_cfg *cfg, uint64_t seed0, int nprob, double *V,
                         double *A, double *G, double *q, double *b, double *g, double *d,
                         double *u, int nthreads);
+/* V may be NULL in the two calls above (only the small arrays are generated); the N x N x T part can
+ * then be produced on the GPU, bit-identical to the host version, straight into device memory: */
+int ssqp_generate_V_dev(ssqp_ctx *ctx, const ssqp_gen_cfg *cfg, uint64_t seed0, int nprob, double *dV,
+                        void *stream);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,7 @@ SIGNATURES = {
     "ssqp_phase1_batch_f64": (C.c_int, [C.c_int] * 4 + [_vp] * 6 + [C.POINTER(CSettings), _vp, _vp, _vp, C.c_int]),
     "ssqp_generate_problem": (C.c_int, [C.POINTER(CGenCfg), C.c_uint64] + [_vp] * 8),
     "ssqp_generate_batch": (C.c_int, [C.POINTER(CGenCfg), C.c_uint64, C.c_int] + [_vp] * 8 + [C.c_int]),
+    "ssqp_generate_V_dev": (C.c_int, [_vp, C.POINTER(CGenCfg), C.c_uint64, C.c_int, _vp, _vp]),
 }
 
 _lib = None

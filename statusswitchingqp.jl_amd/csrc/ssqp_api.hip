@@ -217,6 +217,14 @@ int ssqp_solve_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const 
     return SSQP_OK;
 }
 
+int ssqp_generate_V_dev(ssqp_ctx *c, const ssqp_gen_cfg *cfg, uint64_t seed0, int nprob, double *dV, void *stream) {
+    if (!c || !cfg || !dV || nprob < 0 || cfg->N <= 0 || cfg->T <= 0) return SSQP_ERR_ARG;
+    if (nprob == 0) return SSQP_OK;
+    if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return SSQP_ERR_HIP;
+    return hip_ok(c, ssqp::launch_genV(nprob, cfg->N, cfg->T, cfg->delta, seed0, dV, (hipStream_t)stream), "genV launch")
+               ? SSQP_OK : SSQP_ERR_HIP;
+}
+
 int ssqp_solve_batch_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const double *V, const double *A,
                          const double *G, const double *q, const double *b, const double *g, const double *d,
                          const double *u, int32_t *S, const double *x0, double *z, const ssqp_settings *settings,

@@ -41,7 +41,7 @@ int generate_one(const ssqp_gen_cfg &c, uint64_t seed, double *V, double *A, dou
     const double inf = std::numeric_limits<double>::infinity();
     // V = X'X/T + delta*I; X[t,i] = u01(t + T*i) - 1/2.  The sum over t runs in
     // increasing t for every (i,j): rank-1 accumulation, row t at a time.
-    {
+    if (V) {
         // blocks of TB sample rows per sweep over V; per element the products are still added
         // one at a time in increasing t (bit-identical to the unblocked rank-1 accumulation)
         constexpr int TB = 16;
@@ -443,7 +443,7 @@ void ssqp_default_settings(ssqp_settings *s) {
 
 int ssqp_generate_problem(const ssqp_gen_cfg *cfg, uint64_t seed, double *V, double *A, double *G,
                           double *q, double *b, double *g, double *d, double *u) {
-    if (!cfg || !V || !q || !d || !u) return SSQP_ERR_ARG;
+    if (!cfg || !q || !d || !u) return SSQP_ERR_ARG;  // V may be NULL: see ssqp_generate_V_dev
     if ((cfg->M > 0 && (!A || !b)) || (cfg->J > 0 && (!G || !g))) return SSQP_ERR_ARG;
     return generate_one(*cfg, seed, V, A, G, q, b, g, d, u);
 }
@@ -456,7 +456,7 @@ int ssqp_generate_batch(const ssqp_gen_cfg *cfg, uint64_t seed0, int nprob, doub
     std::atomic<int> rc{SSQP_OK};
     parallel_for(nprob, nthreads, [&](int p) {
         const size_t P = p;
-        int r = ssqp_generate_problem(cfg, seed0 + P, V + P * N * N, A ? A + P * M * N : nullptr,
+        int r = ssqp_generate_problem(cfg, seed0 + P, V ? V + P * N * N : nullptr, A ? A + P * M * N : nullptr,
                                       G ? G + P * J * N : nullptr, q + P * N, b ? b + P * M : nullptr,
                                       g ? g + P * J : nullptr, d + P * N, u + P * N);
         if (r != SSQP_OK) rc = r;

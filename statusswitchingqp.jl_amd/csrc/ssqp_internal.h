@@ -107,6 +107,7 @@ inline size_t global_arena_doubles(int N, int M, int J) {
 
 void launch_prep(int nprob, int N, int M, int J, const double *A, const double *G, const double *b,
                  const double *g, double *Ct, double *rhs, hipStream_t stream);
+hipError_t launch_genV(int nprob, int N, int T, double delta, unsigned long long seed0, double *V, hipStream_t stream);
 hipError_t launch_solve(const SolveParams &P, int grid, size_t ldsBytes, int wgPerCU, hipStream_t stream);
 
 }  // namespace ssqp

@@ -123,6 +123,12 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int srcLane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
+    return __hiloint2double(hi, lo);
+}
+
 struct KeyMin {  // minimum value, ties -> smallest order
     double v;
     int ord;
@@ -613,6 +619,95 @@ __device__ __forceinline__ int rank_filter_wave(double *X, int W0, int nc, doubl
     return nrows;
 }
 
+// The same filter with X held in REGISTERS of one wavefront (W0 <= 8 rows, nc <= 192 columns: lane owns
+// columns lane, lane+64, lane+128): no LDS traffic and no barriers inside the elimination.  The reference's
+// column permutation c0 is tracked as a position per column (a swap of c0[mj] and c0[j] swaps two positions), so
+// the pivot rule -- first maximum in c0 order -- and every arithmetic operation are those of utils.jl:58-83.
+constexpr int RF_ROWS = 8, RF_CS = 3;
+__device__ __forceinline__ int rank_filter_regs(const double *X, int W0, int nc, double tol, const Lds &L) {
+    const int lane = threadIdx.x & 63;
+    double x[RF_CS][RF_ROWS];
+    int posn[RF_CS];
+    const int ncs = (nc + 63) >> 6;
+#pragma unroll
+    for (int cs = 0; cs < RF_CS; ++cs) {
+        const int t = lane + 64 * cs;
+        posn[cs] = (t < nc) ? t : 0x7fff0000;  // dead columns never qualify
+#pragma unroll
+        for (int k = 0; k < RF_ROWS; ++k) x[cs][k] = (cs < ncs && t < nc && k < W0) ? X[k + W0 * (t < nc ? t : 0)] : 0.0;
+    }
+    int i = 0, j = 0, nrows = 0;
+    while (i < W0 && j < nc) {
+        KeyMin best{1.0, 0x7fffffff};
+#pragma unroll
+        for (int cs = 0; cs < RF_CS; ++cs) {
+            if (cs < ncs) {
+                double xi = 0.0;
+#pragma unroll
+                for (int k = 0; k < RF_ROWS; ++k) xi = (k == i) ? x[cs][k] : xi;
+                const bool in = posn[cs] >= j && posn[cs] < nc;
+                const KeyMin cand{in ? -fabs(xi) : 1.0, in ? posn[cs] : 0x7fffffff};
+                best = keymin(best, cand);
+            }
+        }
+        best = wave_keymin(best);
+        const double m = -best.v;
+        const int mpos = best.ord;
+        if (!(m > tol)) {  // utils.jl:61
+            i += 1;
+            continue;
+        }
+        if (lane == 0) L.ra[nrows] = (int16_t)i;
+        nrows += 1;
+        // c0[mj] <-> c0[j]
+#pragma unroll
+        for (int cs = 0; cs < RF_CS; ++cs) {
+            const int pz = posn[cs];
+            posn[cs] = (pz == mpos) ? j : ((pz == j) ? mpos : pz);
+        }
+        // the pivot column (now at position j): broadcast its entries
+        double dcol[RF_ROWS];
+#pragma unroll
+        for (int k = 0; k < RF_ROWS; ++k) dcol[k] = 0.0;
+#pragma unroll
+        for (int cs = 0; cs < RF_CS; ++cs) {
+            if (cs < ncs) {
+                const unsigned long long own = __ballot(posn[cs] == j);
+                if (own) {
+                    const int src = __ffsll((long long)own) - 1;
+#pragma unroll
+                    for (int k = 0; k < RF_ROWS; ++k)
+                        if (k < W0) dcol[k] = readlane_f64(x[cs][k], src);
+                }
+            }
+        }
+        double dd = 0.0;
+#pragma unroll
+        for (int k = 0; k < RF_ROWS; ++k) dd = (k == i) ? dcol[k] : dd;
+#pragma unroll
+        for (int cs = 0; cs < RF_CS; ++cs) {
+            if (cs < ncs) {
+                const bool in = posn[cs] >= j && posn[cs] < nc;
+                double xi = 0.0;
+#pragma unroll
+                for (int k = 0; k < RF_ROWS; ++k) xi = (k == i) ? x[cs][k] : xi;
+                const double xn = xi / dd;  // utils.jl:68-70 (IEEE division, like the reference)
+#pragma unroll
+                for (int k = 0; k < RF_ROWS; ++k) {
+                    if (k < W0) {
+                        const double upd = (k == i) ? xn : sub_mul_nc(x[cs][k], dcol[k], xn);  // utils.jl:71-78
+                        x[cs][k] = in ? upd : x[cs][k];
+                    }
+                }
+            }
+        }
+        i += 1;
+        j += 1;
+    }
+    wave_sync();
+    return nrows;
+}
+
 // --------------------------------------------------- bordered LDL' in the arena
 // fac: packed lower triangle (column j holds rows j..R-1) of the R x R matrix
 //     [ V_FF  .   . ]      R = K + W + 1
@@ -667,11 +762,6 @@ __device__ __forceinline__ bool bordered_ldl1(double *fac, double *rd, int jb, i
 // lane = row, the rows of the 4x4 diagonal block are broadcast with v_readlane -- then all wavefronts apply
 // the rank-4 update to the trailing columns.  Two workgroup barriers per FOUR columns instead of one per
 // column.  Needs R - jb <= 256 (four row slots per lane); otherwise the one-column version runs.
-__device__ __forceinline__ double readlane_f64(double v, int srcLane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
-    return __hiloint2double(hi, lo);
-}
 
 __device__ __forceinline__ bool bordered_ldl(double *fac, double *rd, int jb, int je, int R, const Lds &L) {
     constexpr int RS = 4;
@@ -1022,6 +1112,62 @@ __device__ __forceinline__ void inc_backward(const Inc &I, int K, double &v0, do
     }
 }
 
+// lambda of the Schur system H lam = s (W <= 7), H symmetric (lower part given), one wavefront:
+// lane i holds row i of H and s_i; eliminations broadcast the pivot row with v_readlane.  Returns false
+// when a pivot is not > 0 (the reference's cholesky(C) throws).  On return lane w < W holds lam_w.
+__device__ __forceinline__ bool small_spd_solve(const double *H, const double *rhs_, int W, double &lam) {
+    const int lane = threadIdx.x & 63;
+    double a[INC_RBM - 1];
+#pragma unroll
+    for (int c = 0; c < INC_RBM - 1; ++c) {
+        const int r = lane < W ? lane : 0, cc = c < W ? c : 0;
+        const double v = (r >= cc) ? H[r + W * cc] : H[cc + W * r];  // symmetric read from the lower part
+        a[c] = (lane < W && c < W) ? v : 0.0;
+    }
+    double y = (lane < W) ? rhs_[lane] : 0.0;
+    bool ok = true;
+    double rdiag[INC_RBM - 1];
+#pragma unroll
+    for (int c = 0; c < INC_RBM - 1; ++c) {
+        rdiag[c] = 0.0;
+        if (c < W) {
+            const double d = readlane_f64(a[c], c);
+            if (!(d > 0.0)) ok = false;
+            const double r = fast_rcp(d);
+            rdiag[c] = r;
+            const double yc = readlane_f64(y, c);
+            const double lic = a[c] * r;                 // L(i,c) for this lane's row i
+            if (lane > c) {
+                y = fma(-lic, yc, y);                    // forward substitution rides along
+#pragma unroll
+                for (int c2 = c + 1; c2 < INC_RBM - 1; ++c2)
+                    if (c2 < W) a[c2] = fma(-lic, readlane_f64(a[c], c2), a[c2]);
+            }
+        }
+    }
+    // y_i now holds (L^-1 s)_i ; x = L'^-1 D^-1 y
+#pragma unroll
+    for (int c = 0; c < INC_RBM - 1; ++c)
+        if (c < W && lane == c) y = y * rdiag[c];
+#pragma unroll
+    for (int c = INC_RBM - 2; c >= 1; --c) {
+        if (c < W) {
+            const double xc = readlane_f64(y, c);
+            // L(c, i) for i < c: held by lane c in a[i]; needed by lane i  -> broadcast per i is costly, so
+            // lane i reads it by v_readlane from lane c with its own column index unrolled
+#pragma unroll
+            for (int i2 = 0; i2 < INC_RBM - 2; ++i2) {
+                if (i2 < c) {
+                    const double lci = readlane_f64(a[i2], c) * rdiag[i2];
+                    if (lane == i2) y = fma(-lci, xc, y);
+                }
+            }
+        }
+    }
+    lam = y;
+    return ok;
+}
+
 // ------------------------------------------------------------------ the loop
 struct ProbCtx {
     int N, M, J, MJ;
@@ -1216,8 +1362,11 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     if (W0 > 0) {
         if ((long)W0 * (K + 1) <= 4096) {  // small: one wavefront, no workgroup barriers
             if (wave == 0) {
-                const int w = rank_filter_wave(ar, W0, K + 1, tol, L);
+                SUBPHASE_DECL(trf);
+                const int w = (W0 <= RF_ROWS && K + 1 <= 64 * RF_CS) ? rank_filter_regs(ar, W0, K + 1, tol, L)
+                                                                      : rank_filter_wave(ar, W0, K + 1, tol, L);
                 if (lane == 0) L.ired[2 * NW + 4] = w;
+                SUBPHASE(14, trf);
             }
             __syncthreads();
             W = L.ired[2 * NW + 4];
@@ -1282,36 +1431,13 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             }
         }
         __syncthreads();
-        if (wave == 0 && lane == 0) {  // lambda: H lam = bE + t, alphaL = -lam; W <= 7
-            bool okH = true;
-            for (int c = 0; c < W && okH; ++c) {
-                const double dcc = H[c + W * c];
-                if (!(dcc > 0.0)) {
-                    okH = false;
-                    break;
-                }
-                const double rc = 1.0 / dcc;
-                for (int k2 = c + 1; k2 < W; ++k2) {
-                    const double f = H[k2 + W * c] * rc;
-                    for (int i2 = k2; i2 < W; ++i2) H[i2 + W * k2] = fma(-f, H[i2 + W * c], H[i2 + W * k2]);
-                }
-            }
-            L.ired[2 * NW + 2] = okH ? 1 : 0;
-            if (okH) {
-                for (int w = 0; w < W; ++w) L.aL[w] = L.bE[w] + L.tv[w];
-                for (int c = 0; c < W; ++c) {
-                    const double xc = L.aL[c], rc = 1.0 / H[c + W * c];
-                    for (int i2 = c + 1; i2 < W; ++i2) L.aL[i2] = fma(-H[i2 + W * c] * rc, xc, L.aL[i2]);
-                }
-                for (int c = 0; c < W; ++c) L.aL[c] = L.aL[c] / H[c + W * c];
-                for (int c = W - 1; c >= 0; --c) {
-                    double xc = L.aL[c];
-                    const double rc = 1.0 / H[c + W * c];
-                    for (int i2 = c + 1; i2 < W; ++i2) xc = fma(-H[i2 + W * c] * rc, L.aL[i2], xc);
-                    L.aL[c] = xc;
-                }
-                for (int w = 0; w < W; ++w) L.aL[w] = -L.aL[w];
-            }
+        if (wave == 0) {  // lambda: H lam = bE + t, alphaL = -lam; W <= 7, in registers
+            if (lane < W) L.tv[lane] = L.bE[lane] + L.tv[lane];
+            wave_sync();
+            double lam;
+            const bool okH = small_spd_solve(H, L.tv, W, lam);
+            if (lane < W) L.aL[lane] = -lam;
+            if (lane == 0) L.ired[2 * NW + 2] = okH ? 1 : 0;
         }
         __syncthreads();
         if (!L.ired[2 * NW + 2]) {
@@ -1936,6 +2062,74 @@ static hipError_t launch_one(const SolveParams &P, int grid, size_t ldsBytes, hi
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((ssqp_solve_kernel<VEC, WPS>), dim3(grid), dim3(NT), ldsBytes, stream, P);
+    return hipGetLastError();
+}
+
+
+// ---------------------------------------------------------------- synthetic V on the device
+// Bit-identical to generate_one() in ssqp_host.cpp: X[t,i] = u01(stream X, t + T*i) - 1/2,
+// V[i,j] = (sum over t in increasing order of X[t,i]*X[t,j]) / T + delta*(i==j), products and sums rounded
+// separately (no FMA contraction).  One thread per (i <= j) pair mirrors its result.
+__device__ __forceinline__ unsigned long long gen_mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void ssqp_genV_kernel(int nprob, int N, int T, double delta,
+                                                        unsigned long long seed0, double *__restrict__ V) {
+#pragma clang fp contract(off)
+    constexpr unsigned long long GOLDEN = 0x9E3779B97F4A7C15ull;
+    constexpr int TILE = 16, TB = 64;
+    __shared__ double xi[TB][TILE + 1], xj[TB][TILE + 1];
+    const int tilesPerDim = (N + TILE - 1) / TILE;
+    const int ntile = tilesPerDim * (tilesPerDim + 1) / 2;
+    const int p = blockIdx.x / ntile;
+    if (p >= nprob) return;
+    int tIdx = blockIdx.x - p * ntile, tj = 0;
+    while (tIdx > tj) {  // upper-triangular tile index -> (ti <= tj)
+        tIdx -= tj + 1;
+        ++tj;
+    }
+    const int ti = tIdx;
+    const unsigned long long seed = seed0 + (unsigned long long)p;
+    const unsigned long long base = gen_mix64(gen_mix64(seed + GOLDEN) ^ (1ull * 0xD1B54A32D192ED03ull + GOLDEN));
+    const int li = threadIdx.x & 15, lj = threadIdx.x >> 4;
+    const int i = ti * TILE + li, j = tj * TILE + lj;
+    double acc = 0.0;
+    for (int t0 = 0; t0 < T; t0 += TB) {
+        for (int e = threadIdx.x; e < TB * TILE; e += 256) {
+            const int tt = e / TILE, c = e - tt * TILE;
+            const int t = t0 + tt;
+            const int ci = ti * TILE + c, cj = tj * TILE + c;
+            double a = 0.0, b = 0.0;
+            if (t < T && ci < N)
+                a = (double)(gen_mix64(base + ((unsigned long long)t + (unsigned long long)T * ci + 1ull) * GOLDEN) >> 11) * 0x1.0p-53 - 0.5;
+            if (t < T && cj < N)
+                b = (double)(gen_mix64(base + ((unsigned long long)t + (unsigned long long)T * cj + 1ull) * GOLDEN) >> 11) * 0x1.0p-53 - 0.5;
+            xi[tt][c] = a;
+            xj[tt][c] = b;
+        }
+        __syncthreads();
+        const int tb = (T - t0 < TB) ? T - t0 : TB;
+        for (int tt = 0; tt < tb; ++tt) {
+            const double prod = xi[tt][li] * xj[tt][lj];
+            acc = acc + prod;
+        }
+        __syncthreads();
+    }
+    if (i < N && j < N && i <= j) {
+        double v = acc / (double)T;
+        if (i == j) v = v + delta;
+        double *Vp = V + (size_t)p * N * N;
+        Vp[(size_t)j * N + i] = v;
+        Vp[(size_t)i * N + j] = v;
+    }
+}
+
+hipError_t launch_genV(int nprob, int N, int T, double delta, unsigned long long seed0, double *V, hipStream_t stream) {
+    const int tiles = (N + 15) / 16;
+    const long blocks = (long)nprob * tiles * (tiles + 1) / 2;
+    hipLaunchKernelGGL(ssqp_genV_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, nprob, N, T, delta, seed0, V);
     return hipGetLastError();
 }
 

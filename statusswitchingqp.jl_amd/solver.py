@@ -13,6 +13,7 @@ import os
 import numpy as np
 
 from . import _capi
+from ._capi import SSQPError
 from .types import QP, Settings, Status
 
 _default_ctx = None
@@ -143,10 +144,12 @@ CONFIGS = {
 }
 
 
-def generate_batch(cfg, nprob, seed0=BASE_SEED, nthreads=0):
-    """dict of numpy arrays V,A,G,q,b,g,d,u for problems seed0 .. seed0+nprob-1."""
+def generate_batch(cfg, nprob, seed0=BASE_SEED, nthreads=0, with_V=True):
+    """dict of numpy arrays V,A,G,q,b,g,d,u for problems seed0 .. seed0+nprob-1.  with_V=False leaves V out
+    (it is the expensive part; DeviceBatch.generated makes it on the GPU, bit-identical)."""
     N, M, J = cfg.N, cfg.M, cfg.J
-    out = dict(V=np.zeros((nprob, N, N)), A=np.zeros((nprob, N, M)), G=np.zeros((nprob, N, J)),
+    out = dict(V=np.zeros((nprob, N, N)) if with_V else np.zeros((0, N, N)), A=np.zeros((nprob, N, M)),
+               G=np.zeros((nprob, N, J)),
                q=np.zeros((nprob, N)), b=np.zeros((nprob, M)), g=np.zeros((nprob, J)), d=np.zeros((nprob, N)),
                u=np.zeros((nprob, N)))
     cc = cfg.c()
@@ -203,14 +206,35 @@ def stats_to_numpy(stats):
 class DeviceBatch:
     """A batch resident in HBM (torch tensors hold the memory) + the launch of the in-kernel loop."""
 
-    def __init__(self, prob, S0, x0, ctx=None, ntrace=0, device=None):
+    @classmethod
+    def generated(cls, cfg, nprob, seed0=BASE_SEED, ctx=None, ntrace=0, device=None, nthreads=0):
+        """Synthetic batch with V generated ON the GPU (same bits as the host generator); the small arrays
+        and the Phase-1 vertex come from the host.  Returns (batch, prob_without_V, x0, S0)."""
+        prob = generate_batch(cfg, nprob, seed0, nthreads=nthreads, with_V=False)
+        x0, S0, st = phase1_batch(prob, nthreads=nthreads)
+        if not (st == 1).all():
+            raise SSQPError("Phase-1 failed on a synthetic problem")
+        self = cls(prob, S0, x0, ctx=ctx, ntrace=ntrace, device=device, _gen=(cfg, seed0))
+        return self, prob, x0, S0
+
+    def __init__(self, prob, S0, x0, ctx=None, ntrace=0, device=None, _gen=None):
         import torch
         self.torch = torch
         self.ctx = ctx or default_context()
         dev = torch.device("cuda", self.ctx.device if device is None else device)
         self.P, self.N = prob["q"].shape
         self.M, self.J = prob["b"].shape[1], prob["g"].shape[1]
-        self.t = {k: torch.from_numpy(_f64(prob[k])).to(dev) for k in "VAGqbgdu"}
+        self.t = {k: torch.from_numpy(_f64(prob[k])).to(dev) for k in "AGqbgdu"}
+        if _gen is None:
+            self.t["V"] = torch.from_numpy(_f64(prob["V"])).to(dev)
+        else:
+            cfg, seed0 = _gen
+            self.t["V"] = torch.empty((self.P, self.N, self.N), dtype=torch.float64, device=dev)
+            cc = cfg.c()
+            rc = _capi.lib().ssqp_generate_V_dev(self.ctx.handle, C.byref(cc), seed0, self.P,
+                                                 C.c_void_p(self.t["V"].data_ptr()),
+                                                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            _capi.check(rc, self.ctx.handle)
         self.S0 = torch.from_numpy(np.ascontiguousarray(S0, dtype=np.int32)).to(dev)
         self.x0 = torch.from_numpy(_f64(x0)).to(dev)
         self.S = torch.empty_like(self.S0)

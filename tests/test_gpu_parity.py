@@ -170,3 +170,26 @@ def test_batch_larger_than_grid(pkg, orc):
     """more problems than resident workgroups: the work queue hands several problems to one workgroup"""
     cfg = pkg.GenConfig(96, 1, 4, 192, 1e-3, 0.08, 1.0, 0.1)
     run_cfg(pkg, orc, cfg, 1500)
+
+
+def test_device_generator_is_bit_identical(pkg):
+    """ssqp_generate_V_dev makes exactly the host generator's V (same counter stream, same summation order)."""
+    for cfg in (pkg.GenConfig(48, 1, 2, 70, 1e-3, 0.1, 1.0, 0.1), pkg.GenConfig(130, 2, 3, 64, 0.0, 0.05, 1.0, 0.1)):
+        host = pkg.generate_batch(cfg, 3, 4242)
+        batch, prob, x0, S0 = pkg.DeviceBatch.generated(cfg, 3, 4242)
+        assert np.array_equal(batch.t["V"].cpu().numpy(), host["V"])
+        for k in "AGqbgdu":
+            assert np.array_equal(prob[k], host[k])
+
+
+def test_incremental_and_from_scratch_agree(pkg, orc):
+    """the kept-factor engine (default) and the from-scratch factorisation (SSQP_INCREMENTAL=0) take the same
+    decisions as the oracle"""
+    cfg = pkg.GenConfig(160, 1, 5, 320, 1e-3, 0.06, 0.98, 0.1)
+    for inc in ("1", "0"):
+        os.environ["SSQP_INCREMENTAL"] = inc
+        try:
+            rel, stats = run_cfg(pkg, orc, cfg, 48)
+        finally:
+            os.environ["SSQP_INCREMENTAL"] = "1"
+        assert (((stats["path"] & 4) != 0).all()) == (inc == "1")
