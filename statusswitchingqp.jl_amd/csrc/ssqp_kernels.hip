@@ -624,31 +624,33 @@ __device__ __forceinline__ int rank_filter_wave(double *X, int W0, int nc, doubl
 // column permutation c0 is tracked as a position per column (a swap of c0[mj] and c0[j] swaps two positions), so
 // the pivot rule -- first maximum in c0 order -- and every arithmetic operation are those of utils.jl:58-83.
 constexpr int RF_ROWS = 8, RF_CS = 3;
+// ROWS x CS is the register tile (rows beyond W0 and columns beyond nc hold zeros / a dead position and take
+// part in the arithmetic harmlessly: no guards, straight-line code).
+template <int ROWS, int CS>
 __device__ __forceinline__ int rank_filter_regs(const double *X, int W0, int nc, double tol, const Lds &L) {
     const int lane = threadIdx.x & 63;
-    double x[RF_CS][RF_ROWS];
-    int posn[RF_CS];
-    const int ncs = (nc + 63) >> 6;
+    double x[CS][ROWS];
+    int posn[CS];
 #pragma unroll
-    for (int cs = 0; cs < RF_CS; ++cs) {
+    for (int cs = 0; cs < CS; ++cs) {
         const int t = lane + 64 * cs;
         posn[cs] = (t < nc) ? t : 0x7fff0000;  // dead columns never qualify
 #pragma unroll
-        for (int k = 0; k < RF_ROWS; ++k) x[cs][k] = (cs < ncs && t < nc && k < W0) ? X[k + W0 * (t < nc ? t : 0)] : 0.0;
+        for (int k = 0; k < ROWS; ++k) {
+            const double v = X[(k < W0 ? k : 0) + W0 * (t < nc ? t : 0)];
+            x[cs][k] = (t < nc && k < W0) ? v : 0.0;
+        }
     }
     int i = 0, j = 0, nrows = 0;
     while (i < W0 && j < nc) {
         KeyMin best{1.0, 0x7fffffff};
 #pragma unroll
-        for (int cs = 0; cs < RF_CS; ++cs) {
-            if (cs < ncs) {
-                double xi = 0.0;
+        for (int cs = 0; cs < CS; ++cs) {
+            double xi = 0.0;
 #pragma unroll
-                for (int k = 0; k < RF_ROWS; ++k) xi = (k == i) ? x[cs][k] : xi;
-                const bool in = posn[cs] >= j && posn[cs] < nc;
-                const KeyMin cand{in ? -fabs(xi) : 1.0, in ? posn[cs] : 0x7fffffff};
-                best = keymin(best, cand);
-            }
+            for (int k = 0; k < ROWS; ++k) xi = (k == i) ? x[cs][k] : xi;
+            const bool in = posn[cs] >= j && posn[cs] < nc;
+            best = keymin(best, KeyMin{in ? -fabs(xi) : 1.0, in ? posn[cs] : 0x7fffffff});
         }
         best = wave_keymin(best);
         const double m = -best.v;
@@ -659,46 +661,36 @@ __device__ __forceinline__ int rank_filter_regs(const double *X, int W0, int nc,
         }
         if (lane == 0) L.ra[nrows] = (int16_t)i;
         nrows += 1;
-        // c0[mj] <-> c0[j]
+        // c0[mj] <-> c0[j]; then the pivot column (now at position j) broadcasts its entries
+        double dcol[ROWS];
 #pragma unroll
-        for (int cs = 0; cs < RF_CS; ++cs) {
+        for (int k = 0; k < ROWS; ++k) dcol[k] = 0.0;
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) {
             const int pz = posn[cs];
             posn[cs] = (pz == mpos) ? j : ((pz == j) ? mpos : pz);
-        }
-        // the pivot column (now at position j): broadcast its entries
-        double dcol[RF_ROWS];
+            const unsigned long long own = __ballot(posn[cs] == j);
+            const int src = own ? (__ffsll((long long)own) - 1) : 0;
 #pragma unroll
-        for (int k = 0; k < RF_ROWS; ++k) dcol[k] = 0.0;
-#pragma unroll
-        for (int cs = 0; cs < RF_CS; ++cs) {
-            if (cs < ncs) {
-                const unsigned long long own = __ballot(posn[cs] == j);
-                if (own) {
-                    const int src = __ffsll((long long)own) - 1;
-#pragma unroll
-                    for (int k = 0; k < RF_ROWS; ++k)
-                        if (k < W0) dcol[k] = readlane_f64(x[cs][k], src);
-                }
+            for (int k = 0; k < ROWS; ++k) {
+                const double bv = readlane_f64(x[cs][k], src);
+                dcol[k] = own ? bv : dcol[k];
             }
         }
         double dd = 0.0;
 #pragma unroll
-        for (int k = 0; k < RF_ROWS; ++k) dd = (k == i) ? dcol[k] : dd;
+        for (int k = 0; k < ROWS; ++k) dd = (k == i) ? dcol[k] : dd;
 #pragma unroll
-        for (int cs = 0; cs < RF_CS; ++cs) {
-            if (cs < ncs) {
-                const bool in = posn[cs] >= j && posn[cs] < nc;
-                double xi = 0.0;
+        for (int cs = 0; cs < CS; ++cs) {
+            const bool in = posn[cs] >= j && posn[cs] < nc;
+            double xi = 0.0;
 #pragma unroll
-                for (int k = 0; k < RF_ROWS; ++k) xi = (k == i) ? x[cs][k] : xi;
-                const double xn = xi / dd;  // utils.jl:68-70 (IEEE division, like the reference)
+            for (int k = 0; k < ROWS; ++k) xi = (k == i) ? x[cs][k] : xi;
+            const double xn = xi / dd;  // utils.jl:68-70 (IEEE division, like the reference)
 #pragma unroll
-                for (int k = 0; k < RF_ROWS; ++k) {
-                    if (k < W0) {
-                        const double upd = (k == i) ? xn : sub_mul_nc(x[cs][k], dcol[k], xn);  // utils.jl:71-78
-                        x[cs][k] = in ? upd : x[cs][k];
-                    }
-                }
+            for (int k = 0; k < ROWS; ++k) {
+                const double upd = (k == i) ? xn : sub_mul_nc(x[cs][k], dcol[k], xn);  // utils.jl:71-78
+                x[cs][k] = in ? upd : x[cs][k];
             }
         }
         i += 1;
@@ -925,12 +917,17 @@ struct Inc {
 };
 __device__ __forceinline__ int cofs(int c, int RC) { return c * RC - ((c * (c - 1)) >> 1); }
 
-// value of row r (uniform) from the two register slots
+// value of row r (uniform) from the register slots
+template <int SL>
 __device__ __forceinline__ double row_bcast(double s0, double s1, int r) {
+    if (SL == 1) return readlane_f64(s0, r);
     return (r < 64) ? readlane_f64(s0, r) : readlane_f64(s1, r - 64);
 }
 
+// SL = register slots in use: 1 when K <= 64 (the common case: half the work, no slot selection), else 2.
+
 // Append variable j as row K (wavefront 0 only).  Returns false when the new pivot is not > 0.
+template <int SL>
 __device__ __forceinline__ bool inc_append(const Inc &I, int K, int j, const double *__restrict__ V, int N) {
     const int lane = threadIdx.x & 63;
     const int RC = I.RC;
@@ -938,21 +935,21 @@ __device__ __forceinline__ bool inc_append(const Inc &I, int K, int j, const dou
     const int r0 = lane, r1 = lane + 64;
     const double vjj = col[j];
     double y0 = (r0 < K) ? col[I.ord[r0 < K ? r0 : 0]] : 0.0;
-    double y1 = (r1 < K) ? col[I.ord[r1 < K ? r1 : 0]] : 0.0;
+    double y1 = (SL == 2 && r1 < K) ? col[I.ord[r1 < K ? r1 : 0]] : 0.0;
 #pragma unroll 4
     for (int c = 0; c < K; ++c) {
         const int oc = cofs(c, RC) - c;
         const double l0 = I.fcol[oc + ((r0 > c && r0 < K) ? r0 : c)];
-        const double l1 = I.fcol[oc + ((r1 > c && r1 < K) ? r1 : c)];
-        const double yc = row_bcast(y0, y1, c);
+        const double l1 = (SL == 2) ? I.fcol[oc + ((r1 > c && r1 < K) ? r1 : c)] : 0.0;
+        const double yc = row_bcast<SL>(y0, y1, c);
         y0 = (r0 > c && r0 < K) ? fma(-l0, yc, y0) : y0;
-        y1 = (r1 > c && r1 < K) ? fma(-l1, yc, y1) : y1;
+        if (SL == 2) y1 = (r1 > c && r1 < K) ? fma(-l1, yc, y1) : y1;
     }
     const double t0 = (r0 < K) ? y0 * I.rdv[r0 < K ? r0 : 0] : 0.0;
-    const double t1 = (r1 < K) ? y1 * I.rdv[r1 < K ? r1 : 0] : 0.0;
+    const double t1 = (SL == 2 && r1 < K) ? y1 * I.rdv[r1 < K ? r1 : 0] : 0.0;
     const double dnew = vjj - wave_sum(fma(y0, t0, y1 * t1));
     if (r0 < K) I.fcol[cofs(r0, RC) + K - r0] = t0;
-    if (r1 < K) I.fcol[cofs(r1, RC) + K - r1] = t1;
+    if (SL == 2 && r1 < K) I.fcol[cofs(r1, RC) + K - r1] = t1;
     if (lane == 0) {
         I.fcol[cofs(K, RC)] = dnew;
         I.rdv[K] = fast_rcp(dnew);
@@ -964,34 +961,35 @@ __device__ __forceinline__ bool inc_append(const Inc &I, int K, int j, const dou
 }
 
 // Rank-1 part of deleting row p: L33 D3 L33' += d_p l l'  (wavefront 0 only).
+template <int SL>
 __device__ __forceinline__ void inc_delete_update(const Inc &I, int K, int p) {
     const int lane = threadIdx.x & 63;
     const int RC = I.RC;
     const int r0 = lane, r1 = lane + 64;
     double d0 = (r0 < K) ? I.fcol[cofs(r0 < K ? r0 : 0, RC)] : 1.0;
-    double d1 = (r1 < K) ? I.fcol[cofs(r1 < K ? r1 : 0, RC)] : 1.0;
+    double d1 = (SL == 2 && r1 < K) ? I.fcol[cofs(r1 < K ? r1 : 0, RC)] : 1.0;
     const int op = cofs(p, RC) - p;
     double w0 = (r0 > p && r0 < K) ? I.fcol[op + r0] : 0.0;
-    double w1 = (r1 > p && r1 < K) ? I.fcol[op + r1] : 0.0;
-    double alpha = row_bcast(d0, d1, p);
+    double w1 = (SL == 2 && r1 > p && r1 < K) ? I.fcol[op + r1] : 0.0;
+    double alpha = row_bcast<SL>(d0, d1, p);
     for (int k = p + 1; k < K; ++k) {
         const int ok = cofs(k, RC) - k;
         double l0 = I.fcol[ok + ((r0 > k && r0 < K) ? r0 : k)];
-        double l1 = I.fcol[ok + ((r1 > k && r1 < K) ? r1 : k)];
-        const double pk = row_bcast(w0, w1, k);
-        const double dk = row_bcast(d0, d1, k);
+        double l1 = (SL == 2) ? I.fcol[ok + ((r1 > k && r1 < K) ? r1 : k)] : 0.0;
+        const double pk = row_bcast<SL>(w0, w1, k);
+        const double dk = row_bcast<SL>(d0, d1, k);
         const double dn = fma(alpha * pk, pk, dk);
         const double rdn = fast_rcp(dn);
         const double beta = pk * alpha * rdn;
         alpha = alpha * dk * rdn;
         if (r0 == k) d0 = dn;
-        if (r1 == k) d1 = dn;
+        if (SL == 2 && r1 == k) d1 = dn;
         if (r0 > k && r0 < K) {
             w0 = fma(-pk, l0, w0);
             l0 = fma(beta, w0, l0);
             I.fcol[ok + r0] = l0;
         }
-        if (r1 > k && r1 < K) {
+        if (SL == 2 && r1 > k && r1 < K) {
             w1 = fma(-pk, l1, w1);
             l1 = fma(beta, w1, l1);
             I.fcol[ok + r1] = l1;
@@ -1001,7 +999,7 @@ __device__ __forceinline__ void inc_delete_update(const Inc &I, int K, int p) {
         I.fcol[cofs(r0, RC)] = d0;
         I.rdv[r0] = fast_rcp(d0);
     }
-    if (r1 > p && r1 < K) {
+    if (SL == 2 && r1 > p && r1 < K) {
         I.fcol[cofs(r1, RC)] = d1;
         I.rdv[r1] = fast_rcp(d1);
     }
@@ -1060,6 +1058,7 @@ __device__ __forceinline__ void inc_delete_compact(const Inc &I, int K, int p) {
 
 // Forward substitution L y = b for the border right-hand sides, in place in I.Y.  Right-hand side k of the
 // list (physical column phys[k] of Y) is taken by wavefront k & (NW-1): no exchange between wavefronts.
+template <int SL>
 __device__ __forceinline__ void inc_forward_border(const Inc &I, int K, int nrhs, const int16_t *phys) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int RC = I.RC;
@@ -1069,33 +1068,34 @@ __device__ __forceinline__ void inc_forward_border(const Inc &I, int K, int nrhs
     const bool two = b1 < nrhs;
     double *Y0 = I.Y + (size_t)phys[b0] * RC;
     double *Y1 = I.Y + (size_t)phys[two ? b1 : b0] * RC;
-    double y00 = (r0 < K) ? Y0[r0] : 0.0, y01 = (r1 < K) ? Y0[r1] : 0.0;
-    double y10 = (r0 < K) ? Y1[r0] : 0.0, y11 = (r1 < K) ? Y1[r1] : 0.0;
+    double y00 = (r0 < K) ? Y0[r0] : 0.0, y01 = (SL == 2 && r1 < K) ? Y0[r1] : 0.0;
+    double y10 = (r0 < K) ? Y1[r0] : 0.0, y11 = (SL == 2 && r1 < K) ? Y1[r1] : 0.0;
 #pragma unroll 4
     for (int c = 0; c < K; ++c) {
         const int oc = cofs(c, RC) - c;
         const double l0 = I.fcol[oc + ((r0 > c && r0 < K) ? r0 : c)];
-        const double l1 = I.fcol[oc + ((r1 > c && r1 < K) ? r1 : c)];
-        const double ya = row_bcast(y00, y01, c);
-        const double yb = row_bcast(y10, y11, c);
-        if (r0 > c && r0 < K) {
-            y00 = fma(-l0, ya, y00);
-            y10 = fma(-l0, yb, y10);
-        }
-        if (r1 > c && r1 < K) {
-            y01 = fma(-l1, ya, y01);
-            y11 = fma(-l1, yb, y11);
+        const double l1 = (SL == 2) ? I.fcol[oc + ((r1 > c && r1 < K) ? r1 : c)] : 0.0;
+        const double ya = row_bcast<SL>(y00, y01, c);
+        const double yb = row_bcast<SL>(y10, y11, c);
+        const bool u0 = r0 > c && r0 < K;
+        y00 = u0 ? fma(-l0, ya, y00) : y00;
+        y10 = u0 ? fma(-l0, yb, y10) : y10;
+        if (SL == 2) {
+            const bool u1 = r1 > c && r1 < K;
+            y01 = u1 ? fma(-l1, ya, y01) : y01;
+            y11 = u1 ? fma(-l1, yb, y11) : y11;
         }
     }
     if (r0 < K) Y0[r0] = y00;
-    if (r1 < K) Y0[r1] = y01;
+    if (SL == 2 && r1 < K) Y0[r1] = y01;
     if (two) {
         if (r0 < K) Y1[r0] = y10;
-        if (r1 < K) Y1[r1] = y11;
+        if (SL == 2 && r1 < K) Y1[r1] = y11;
     }
 }
 
-// Back substitution L' x = v (unit upper), v in two register slots, wavefront 0 only.
+// Back substitution L' x = v (unit upper), v in the register slots, wavefront 0 only.
+template <int SL>
 __device__ __forceinline__ void inc_backward(const Inc &I, int K, double &v0, double &v1) {
     const int lane = threadIdx.x & 63;
     const int RC = I.RC;
@@ -1105,10 +1105,10 @@ __device__ __forceinline__ void inc_backward(const Inc &I, int K, double &v0, do
 #pragma unroll 4
     for (int r = K - 1; r > 0; --r) {
         const double l0 = I.fcol[o0 + (c0 < r ? r : (c0 < K ? c0 : 0))];  // L(r, c0): row r of column c0
-        const double l1 = I.fcol[o1 + (c1 < r ? r : (c1 < K ? c1 : 0))];
-        const double xr = row_bcast(v0, v1, r);
-        if (c0 < r) v0 = fma(-l0, xr, v0);
-        if (c1 < r) v1 = fma(-l1, xr, v1);
+        const double l1 = (SL == 2) ? I.fcol[o1 + (c1 < r ? r : (c1 < K ? c1 : 0))] : 0.0;
+        const double xr = row_bcast<SL>(v0, v1, r);
+        v0 = (c0 < r) ? fma(-l0, xr, v0) : v0;
+        if (SL == 2) v1 = (c1 < r) ? fma(-l1, xr, v1) : v1;
     }
 }
 
@@ -1261,7 +1261,10 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
                 pdel = 63 - __clzll(dm0);
                 dm0 &= ~(1ull << pdel);
             }
-            if (wave == 0) inc_delete_update(I, Kf, pdel);
+            if (wave == 0) {
+                if (Kf <= 64) inc_delete_update<1>(I, Kf, pdel);
+                else inc_delete_update<2>(I, Kf, pdel);
+            }
             __syncthreads();
             inc_delete_compact(I, Kf, pdel);
             Kf -= 1;
@@ -1294,7 +1297,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         bool okA = true;
         for (int a = 0; a < nA; ++a) {
             if (wave == 0) {
-                const bool ok1 = inc_append(I, Kf, L.perm[a], V, N);
+                const bool ok1 = (Kf <= 64) ? inc_append<1>(I, Kf, L.perm[a], V, N) : inc_append<2>(I, Kf, L.perm[a], V, N);
                 if (lane == 0) L.ired[2 * NW + 5] = ok1 ? 1 : 0;
             }
             __syncthreads();
@@ -1363,8 +1366,10 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         if ((long)W0 * (K + 1) <= 4096) {  // small: one wavefront, no workgroup barriers
             if (wave == 0) {
                 SUBPHASE_DECL(trf);
-                const int w = (W0 <= RF_ROWS && K + 1 <= 64 * RF_CS) ? rank_filter_regs(ar, W0, K + 1, tol, L)
-                                                                      : rank_filter_wave(ar, W0, K + 1, tol, L);
+                int w;
+                if (W0 <= 4 && K + 1 <= 128) w = rank_filter_regs<4, 2>(ar, W0, K + 1, tol, L);
+                else if (W0 <= RF_ROWS && K + 1 <= 64 * RF_CS) w = rank_filter_regs<RF_ROWS, RF_CS>(ar, W0, K + 1, tol, L);
+                else w = rank_filter_wave(ar, W0, K + 1, tol, L);
                 if (lane == 0) L.ired[2 * NW + 4] = w;
                 SUBPHASE(14, trf);
             }
@@ -1402,7 +1407,8 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         if (tid <= W) L.perm[tid] = (tid < W) ? L.ra[tid] : (int16_t)W0;  // physical right-hand sides
         __syncthreads();
         PHASE(C, 4);
-        inc_forward_border(I, K, W + 1, L.perm);
+        if (K <= 64) inc_forward_border<1>(I, K, W + 1, L.perm);
+        else inc_forward_border<2>(I, K, W + 1, L.perm);
         __syncthreads();
         PHASE(C, 5);
         // Schur block: H = AE V^-1 AE' (W x W, lower) into the scratch arena, t = AE V^-1 c into tv
@@ -1458,7 +1464,8 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             }
             v0 *= (r0 < K) ? I.rdv[r0] : 0.0;
             v1 *= (r1 < K) ? I.rdv[r1] : 0.0;
-            inc_backward(I, K, v0, v1);
+            if (K <= 64) inc_backward<1>(I, K, v0, v1);
+            else inc_backward<2>(I, K, v0, v1);
             if (r0 < K) L.gam[I.ord[r0]] = -v0;
             if (r1 < K) L.gam[I.ord[r1]] = -v1;
         }
