@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--config", default="cfg4", help="problem family (statusswitchingqp.jl_amd CONFIGS)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--skip-dense", action="store_true",
+                    help="do not time the dense-formulation launches (profiling runs want one kernel variant)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"),
                     help="per-launch HBM bytes from a separate rocprofv3 --pmc pass, if present")
     args = ap.parse_args()
@@ -110,20 +112,26 @@ def main():
     k_ms = float(np.mean(timed_launches(3) + [last_kernel_ms]))
     # the same kernel with the gamma pass reading EVERY column of V, as the reference's dense
     # V[B,F]*alpha + V[B,B]*zB does (SSQP.jl:352): the HBM-bound formulation, timed beside the default one
-    os.environ["SSQP_DENSE_GAMMA"] = "1"
-    dense_ms = float(np.mean(timed_launches(2)))
-    res_dense = batch.results()
-    dense_same = bool(np.array_equal(res_dense["S"], res["S"]) and np.array_equal(res_dense["status"], res["status"]))
-    dense_read = int(res_dense["stats"]["read_bytes"].sum())
-    os.environ["SSQP_DENSE_GAMMA"] = "0"
+    dense = None
+    if not args.skip_dense and os.environ.get("SSQP_DENSE_GAMMA", "0") in ("", "0"):
+        os.environ["SSQP_DENSE_GAMMA"] = "1"
+        dense_ms = float(np.mean(timed_launches(2)))
+        res_dense = batch.results()
+        os.environ["SSQP_DENSE_GAMMA"] = "0"
+        dense = {"ms": dense_ms, "read": int(res_dense["stats"]["read_bytes"].sum()),
+                 "same": bool(np.array_equal(res_dense["S"], res["S"]) and
+                              np.array_equal(res_dense["status"], res["status"]))}
 
     traffic = None
+    traffic_dense = None
     if os.path.exists(args.traffic_json):
         try:
             with open(args.traffic_json) as f:
                 tj = json.load(f)
             if tj.get("config") == args.config and tj.get("nprob") == args.nprob:
-                traffic = tj.get("hbm_bytes_per_launch")
+                key = "dense_formulation" if os.environ.get("SSQP_DENSE_GAMMA", "0") not in ("", "0") else "default_formulation"
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch", tj.get("hbm_bytes_per_launch"))
+                traffic_dense = tj.get("dense_formulation", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -131,7 +139,6 @@ def main():
     if rank == 0:
         qps = world * P * args.steps / elapsed
         achieved = read_bytes / (k_ms * 1e-3) / 1e9
-        dense_achieved = dense_read / (dense_ms * 1e-3) / 1e9
         out = {
             "metric": "QPs/sec (batched N=512 dense portfolio QP, solveQP(Q,S,x0) to KKT)",
             "value": qps, "unit": "QPs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -145,14 +152,17 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "ssqp_solve_kernel", "kernel_ms": k_ms, "alg_bytes_per_launch": read_bytes,
-                         "note": "default formulation skips the columns of V whose weight in the gamma pass is "
-                                 "exactly 0 (bound variables at d=0): the loop is latency-bound, not HBM-bound"},
-            "roofline_dense_formulation": {
-                "bound": "hbm", "achieved": dense_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dense_achieved / HBM_PEAK_GBS, "kernel_ms": dense_ms, "alg_bytes_per_launch": dense_read,
-                "reference_formula_bytes": dense_bytes, "same_S_and_iters": dense_same,
-                "qps": P / (dense_ms * 1e-3),
-                "note": "same kernel, SSQP_DENSE_GAMMA=1: gamma pass reads all N columns like SSQP.jl:352"},
+                         "note": "default formulation: kept LDL' factor (append/delete) and a gamma pass that skips the "
+                                 "columns of V whose weight is exactly 0 (bound variables at d=0): the loop is "
+                                 "latency-bound (dependent single-wavefront chains), not HBM-bound"},
+            "roofline_dense_formulation": None if dense is None else {
+                "bound": "hbm", "achieved": dense["read"] / (dense["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": dense["read"] / (dense["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": traffic_dense, "kernel_ms": dense["ms"], "alg_bytes_per_launch": dense["read"],
+                "reference_formula_bytes": dense_bytes, "same_S_and_iters": dense["same"],
+                "qps": P / (dense["ms"] * 1e-3),
+                "note": "same kernel with SSQP_DENSE_GAMMA=1: from-scratch factorisation and a gamma pass that reads "
+                        "all N columns of V like SSQP.jl:322,352 -- the HBM-bound formulation of the reference"},
             "setup_s": t_setup,
         }
         if not args.no_cpu and world == 1:

@@ -20,8 +20,10 @@ db.solve(); db.results()
 lib.ssqp_debug_phases(out, 1)
 db.solve(); res = db.results()
 lib.ssqp_debug_phases(out, 1)
-names = ["compaction+lists", "E-row sweep", "rank filter", "pass1 V[:,F]+gather", "bordered LDL", "Schur+lambda",
-         "vk+back-subst", "alpha/p/norm", "aStep", "pass2 V[:,B] gamma", "KKTchk", "load/polish/store", "freeK", "ldl:panel(w0)", "ldl:update", "ldl:barrier-wait"]
+names = ["compaction+lists", "E-row sweep + Y copy", "rank filter (+barriers)", "hB pass V[:,nzB] + c   [old: pass1]",
+         "forward border          [old: LDL]", "Schur + lambda", "v + back-substitution", "alpha/p/norm", "aStep",
+         "gamma pass V[:,nz]", "KKTchk", "load/polish/store", "freeK", "factor sync (del/app)",
+         "(sub) rank filter body / old LDL update", "(sub) old LDL panel"]
 tot = sum(out)
 iters = int(res["status"].sum())
 print("config", name, "nprob", nprob, "total iterations", iters, "kernel ms", db.ctx.last_kernel_ms())
