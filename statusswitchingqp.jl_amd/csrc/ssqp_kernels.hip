@@ -1,32 +1,29 @@
 // ssqp_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the active-set inner loop.
 //
-// One 512-thread workgroup owns one QP and runs the WHOLE solveQP(Q,S,x0) loop
-// (reference: src/SSQP.jl:237-377) in-kernel: no host round trip per iteration.
-// Workgroups are persistent and pull problem ids from a device counter.
+// One 256-thread workgroup (4 wavefronts) owns one QP and runs the WHOLE solveQP(Q,S,x0) loop
+// (reference: src/SSQP.jl:237-377) in-kernel: no host round trip per iteration.  Workgroups are persistent
+// (two per CU) and pull problem ids from a device counter.
 //
-// Per loop pass (names follow the reference):
-//   compaction      F = (S .== IN), index lists               SSQP.jl:276-289
-//   E-row sweep     bE = [b; g[Eg]] - AB*zB, X = [AE bE]      SSQP.jl:290-295
-//   rank filter     getRowsGJr(X, tol)                        utils.jl:49-86
-//   pass 1          stream V[:,F]: c = V[B,F]'zB + q[F] and the K x K gather
-//                   V[F,F] straight into the LDS factor        SSQP.jl:322-324
-//   KKT solve       bordered LDL' of [V_FF AE' c] in LDS, Schur system
-//                   (AE V_FF^-1 AE') lambda = bE + AE V_FF^-1 c, one back
-//                   substitution for alpha                     SSQP.jl:325-332
-//   aStep!          ratio test as workgroup min-reduction      SSQP.jl:61-134
-//   pass 2          stream V[:,B]: gamma                       SSQP.jl:351-352
-//   KKTchk!         (value, order) argmin                      SSQP.jl:136-188
-//   polishSz!                                                  SSQP.jl:10-32
-//   freeK!          K == 0 pass                                SSQP.jl:35-59
+// Per loop pass (names follow the reference; DESIGN.md section 4 has the long version):
+//   compaction      F = (S .== IN), index lists                      SSQP.jl:276-289
+//   factor sync     the LDL' factor of V[F,F] is KEPT across passes: append a released variable,
+//                   delete a blocked one (replaces inv(cholesky(V[F,F])) from scratch, SSQP.jl:322)
+//   E-row sweep     bE = [b; g[Eg]] - AB*zB, X = [AE bE]             SSQP.jl:290-295
+//   rank filter     getRowsGJr(X, tol), operation for operation      utils.jl:49-86
+//   c               V[:,nz(zB)] zB in AXPY form, c = hB[F] + q[F]    SSQP.jl:323-324
+//   KKT solve       forward substitution of the border [AE' c], Schur system
+//                   (AE V_FF^-1 AE') lambda = bE + AE V_FF^-1 c, one back substitution   SSQP.jl:325-332
+//   aStep!          ratio test as workgroup min-reduction            SSQP.jl:61-134
+//   gamma pass      V[:,nz] [alpha; zB], zero-weight columns skipped SSQP.jl:351-352
+//   KKTchk!         (value, order) argmin                            SSQP.jl:136-188
+//   polishSz!                                                        SSQP.jl:10-32
+//   freeK!          K == 0 pass                                      SSQP.jl:35-59
+// plus the from-scratch path (pass 1 over V[:,F] with the V[F,F] gather fused in, panel LDL' of the
+// bordered matrix) for the cases the kept-factor engine does not cover.
 //
-// The reference forms inv(cholesky(V[F,F])) and inv(cholesky(C)) explicitly;
-// this kernel factors and solves (same KKT system).
-// Status decisions are threshold tests far above rounding noise, so S matches
-// bit for bit away from exact ties; z/lambda agree to ~1e-13 relative.
-//
-// HBM traffic per pass is the two column sweeps of V (K columns, then N-K
-// columns, each column read once, 16 B per lane, a full 1 KiB per wave
-// instruction); everything else lives in LDS.
+// The reference forms inv(cholesky(V[F,F])) and inv(cholesky(C)) explicitly; this kernel factors and
+// solves (same KKT system).  Status decisions are threshold tests far above
+// rounding noise, so S matches bit for bit away from exact ties; z/lambda agree to ~1e-13 relative.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions():
     src = open(os.path.join(ROOT, "include", "ssqp_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(ssqp_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(ssqp_[A-Za-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol(pkg):
