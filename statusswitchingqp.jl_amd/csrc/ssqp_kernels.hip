@@ -566,14 +566,9 @@ __device__ __forceinline__ int rank_filter_wave(double *X, int W0, int nc, doubl
     int i = 0, j = 0, nrows = 0;
     while (i < W0 && j < nc) {
         KeyMin best{1.0, 0x7fffffff};  // maximise |x| == minimise -|x|; 1.0 never wins
-        bool any = false;
         for (int t = j + lane; t < nc; t += 64) {
             const double v = -fabs(X[i + W0 * (int)L.perm[t]]);
-            if (!any || v < best.v) {
-                best.v = v;
-                best.ord = t;
-                any = true;
-            }
+            best = keymin(best, KeyMin{v, t});
         }
         best = wave_keymin(best);
         const double m = -best.v;
@@ -592,24 +587,20 @@ __device__ __forceinline__ int rank_filter_wave(double *X, int W0, int nc, doubl
         wave_sync();
         const int n = L.perm[j];
         const double dd = X[i + W0 * n];
-        wave_sync();
-        for (int t = j + lane; t < nc; t += 64) {
-            const int c = L.perm[t];
-            X[i + W0 * c] = X[i + W0 * c] / dd;
-        }
         for (int k = lane; k < W0; k += 64) L.dcol[k] = X[k + W0 * n];
         wave_sync();
-        if (W0 > 1) {
-            const int span = nc - j;
-            for (int e = lane; e < span * W0; e += 64) {
-                const int k = e % W0, t = j + e / W0;
-                if (k != i) {
-                    const int c = L.perm[t];
-                    X[k + W0 * c] = sub_mul_nc(X[k + W0 * c], L.dcol[k], X[i + W0 * c]);
-                }
-            }
-            wave_sync();
+        // Lanes over the columns c0[j:nc]; rows 0..i-1 are never read again by the filter (every later decision
+        // looks at a row below), so only row i is normalised and rows i+1.. are eliminated: same values in
+        // every entry that can still influence a decision as the reference's full Gauss-Jordan sweep.
+        for (int t = j + lane; t < nc; t += 64) {
+            const int c = L.perm[t];
+            double *col = X + W0 * c;
+            const double xn = col[i] / dd;
+            col[i] = xn;
+#pragma unroll 4
+            for (int k = i + 1; k < W0; ++k) col[k] = sub_mul_nc(col[k], L.dcol[k], xn);
         }
+        wave_sync();
         i += 1;
         j += 1;
     }
@@ -620,7 +611,7 @@ __device__ __forceinline__ int rank_filter_wave(double *X, int W0, int nc, doubl
 // columns lane, lane+64, lane+128): no LDS traffic and no barriers inside the elimination.  The reference's
 // column permutation c0 is tracked as a position per column (a swap of c0[mj] and c0[j] swaps two positions), so
 // the pivot rule -- first maximum in c0 order -- and every arithmetic operation are those of utils.jl:58-83.
-constexpr int RF_ROWS = 8, RF_CS = 3;
+constexpr int RF_ROWS = 12, RF_CS = 3;
 // ROWS x CS is the register tile (rows beyond W0 and columns beyond nc hold zeros / a dead position and take
 // part in the arithmetic harmlessly: no guards, straight-line code).
 template <int ROWS, int CS>
@@ -904,7 +895,7 @@ __device__ __forceinline__ void back_substitute(const double *fac, const double 
 // so appending a row moves nothing): slot 0 is d_c, the rest L(r,c).  Rows are spread over lanes: row r is
 // lane r&63 of register slot r>>6 (two slots: K <= 128).
 // =====================================================================================================
-constexpr int INC_RBM = 8;    // border right-hand sides the engine carries (W + 1 <= 8)
+constexpr int INC_RBM = 12;   // border right-hand sides the engine carries (W + 1 <= 12)
 constexpr int INC_KMAX = 128; // two register slots of 64 rows
 
 struct Inc {
@@ -1060,34 +1051,35 @@ __device__ __forceinline__ void inc_forward_border(const Inc &I, int K, int nrhs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int RC = I.RC;
     const int r0 = lane, r1 = lane + 64;
-    const int b0 = wave, b1 = wave + NW;
-    if (b0 >= nrhs) return;
-    const bool two = b1 < nrhs;
-    double *Y0 = I.Y + (size_t)phys[b0] * RC;
-    double *Y1 = I.Y + (size_t)phys[two ? b1 : b0] * RC;
-    double y00 = (r0 < K) ? Y0[r0] : 0.0, y01 = (SL == 2 && r1 < K) ? Y0[r1] : 0.0;
-    double y10 = (r0 < K) ? Y1[r0] : 0.0, y11 = (SL == 2 && r1 < K) ? Y1[r1] : 0.0;
+    for (int b0 = wave; b0 < nrhs; b0 += 2 * NW) {
+        const int b1 = b0 + NW;
+        const bool two = b1 < nrhs;
+        double *Y0 = I.Y + (size_t)phys[b0] * RC;
+        double *Y1 = I.Y + (size_t)phys[two ? b1 : b0] * RC;
+        double y00 = (r0 < K) ? Y0[r0] : 0.0, y01 = (SL == 2 && r1 < K) ? Y0[r1] : 0.0;
+        double y10 = (r0 < K) ? Y1[r0] : 0.0, y11 = (SL == 2 && r1 < K) ? Y1[r1] : 0.0;
 #pragma unroll 4
-    for (int c = 0; c < K; ++c) {
-        const int oc = cofs(c, RC) - c;
-        const double l0 = I.fcol[oc + ((r0 > c && r0 < K) ? r0 : c)];
-        const double l1 = (SL == 2) ? I.fcol[oc + ((r1 > c && r1 < K) ? r1 : c)] : 0.0;
-        const double ya = row_bcast<SL>(y00, y01, c);
-        const double yb = row_bcast<SL>(y10, y11, c);
-        const bool u0 = r0 > c && r0 < K;
-        y00 = u0 ? fma(-l0, ya, y00) : y00;
-        y10 = u0 ? fma(-l0, yb, y10) : y10;
-        if (SL == 2) {
-            const bool u1 = r1 > c && r1 < K;
-            y01 = u1 ? fma(-l1, ya, y01) : y01;
-            y11 = u1 ? fma(-l1, yb, y11) : y11;
+        for (int c = 0; c < K; ++c) {
+            const int oc = cofs(c, RC) - c;
+            const double l0 = I.fcol[oc + ((r0 > c && r0 < K) ? r0 : c)];
+            const double l1 = (SL == 2) ? I.fcol[oc + ((r1 > c && r1 < K) ? r1 : c)] : 0.0;
+            const double ya = row_bcast<SL>(y00, y01, c);
+            const double yb = row_bcast<SL>(y10, y11, c);
+            const bool u0 = r0 > c && r0 < K;
+            y00 = u0 ? fma(-l0, ya, y00) : y00;
+            y10 = u0 ? fma(-l0, yb, y10) : y10;
+            if (SL == 2) {
+                const bool u1 = r1 > c && r1 < K;
+                y01 = u1 ? fma(-l1, ya, y01) : y01;
+                y11 = u1 ? fma(-l1, yb, y11) : y11;
+            }
         }
-    }
-    if (r0 < K) Y0[r0] = y00;
-    if (SL == 2 && r1 < K) Y0[r1] = y01;
-    if (two) {
-        if (r0 < K) Y1[r0] = y10;
-        if (SL == 2 && r1 < K) Y1[r1] = y11;
+        if (r0 < K) Y0[r0] = y00;
+        if (SL == 2 && r1 < K) Y0[r1] = y01;
+        if (two) {
+            if (r0 < K) Y1[r0] = y10;
+            if (SL == 2 && r1 < K) Y1[r1] = y11;
+        }
     }
 }
 
@@ -1109,7 +1101,173 @@ __device__ __forceinline__ void inc_backward(const Inc &I, int K, double &v0, do
     }
 }
 
-// lambda of the Schur system H lam = s (W <= 7), H symmetric (lower part given), one wavefront:
+
+// ---------------------------------------------------------------------------------------------------
+// Wavefront-specialised front half of a pass.  Factor sync, E-row sweep + rank filter and the hB stream are
+// independent of each other, and each is a chain a single wavefront walks; run as three concurrent chains
+// (wavefront 0 / wavefront 1 / wavefronts 2-3) they cost the longest one instead of the sum.  No workgroup
+// barrier may be used inside any of the three (the wavefronts are on different code paths).
+// ---------------------------------------------------------------------------------------------------
+
+// single-wavefront version of inc_delete_compact (wavefront 0)
+__device__ __forceinline__ void inc_delete_compact_w0(const Inc &I, int K, int p) {
+    const int lane = threadIdx.x & 63;
+    const int RC = I.RC;
+    const int r0 = lane, r1 = lane + 64;
+    const bool m0 = r0 > p && r0 < K, m1 = r1 > p && r1 < K;
+    for (int c = 0; c < p; ++c) {  // (A) columns c < p lose row p
+        const int oc = cofs(c, RC) - c;
+        const double a0 = m0 ? I.fcol[oc + r0] : 0.0;
+        const double a1 = m1 ? I.fcol[oc + r1] : 0.0;
+        wave_sync();
+        if (m0) I.fcol[oc + r0 - 1] = a0;
+        if (m1) I.fcol[oc + r1 - 1] = a1;
+    }
+    {
+        const double q0 = m0 ? I.rdv[r0] : 0.0, q1 = m1 ? I.rdv[r1] : 0.0;
+        const int v0 = m0 ? I.ord[r0] : 0, v1 = m1 ? I.ord[r1] : 0;
+        const int vdel = I.ord[p];
+        wave_sync();
+        if (lane == 0) I.fpos[vdel] = -1;
+        if (m0) {
+            I.rdv[r0 - 1] = q0;
+            I.ord[r0 - 1] = (int16_t)v0;
+            I.fpos[v0] = (int16_t)(r0 - 1);
+        }
+        if (m1) {
+            I.rdv[r1 - 1] = q1;
+            I.ord[r1 - 1] = (int16_t)v1;
+            I.fpos[v1] = (int16_t)(r1 - 1);
+        }
+    }
+    for (int c = p + 1; c < K; ++c) {  // (B) column c -> c-1, ascending: the target was vacated one step earlier
+        const int oc = cofs(c, RC) - c, on = cofs(c - 1, RC) - (c - 1);
+        const bool n0 = r0 >= c && r0 < K, n1 = r1 >= c && r1 < K;
+        const double a0 = n0 ? I.fcol[oc + r0] : 0.0;
+        const double a1 = n1 ? I.fcol[oc + r1] : 0.0;
+        wave_sync();
+        if (n0) I.fcol[on + r0 - 1] = a0;
+        if (n1) I.fcol[on + r1 - 1] = a1;
+    }
+    wave_sync();
+}
+
+// factor sync by wavefront 0 alone.  Returns the new row count, or -1 when an appended pivot is not > 0.
+__device__ __forceinline__ int inc_sync_w0(const Inc &I, int Kf, const Lds &L, const double *__restrict__ V, int N,
+                                           int &nAppended) {
+    const int lane = threadIdx.x & 63;
+    nAppended = 0;
+    if (Kf < 0) {
+        for (int i = lane; i < N; i += 64) L.fpos[i] = -1;
+        Kf = 0;
+        wave_sync();
+    }
+    {
+        const int r0 = lane, r1 = lane + 64;
+        const bool dead0 = (r0 < Kf) && (L.S[I.ord[r0 < Kf ? r0 : 0]] != SSQP_IN);
+        const bool dead1 = (r1 < Kf) && (L.S[I.ord[r1 < Kf ? r1 : 0]] != SSQP_IN);
+        unsigned long long dm0 = __ballot(dead0), dm1 = __ballot(dead1);
+        while (dm0 | dm1) {
+            int pdel;
+            if (dm1) {
+                pdel = 127 - __clzll(dm1);
+                dm1 &= ~(1ull << (pdel - 64));
+            } else {
+                pdel = 63 - __clzll(dm0);
+                dm0 &= ~(1ull << pdel);
+            }
+            if (Kf <= 64) inc_delete_update<1>(I, Kf, pdel);
+            else inc_delete_update<2>(I, Kf, pdel);
+            inc_delete_compact_w0(I, Kf, pdel);
+            Kf -= 1;
+        }
+    }
+    for (int c0 = 0; c0 < N; c0 += 64) {
+        const int i = c0 + lane;
+        const bool f = (i < N) && (L.S[i] == SSQP_IN) && (L.fpos[i] < 0);
+        unsigned long long m = __ballot(f);
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const bool ok1 = (Kf <= 64) ? inc_append<1>(I, Kf, c0 + b, V, N) : inc_append<2>(I, Kf, c0 + b, V, N);
+            if (!ok1) return -1;
+            Kf += 1;
+            nAppended += 1;
+        }
+    }
+    return Kf;
+}
+
+// hB partial vector of one of the two streaming wavefronts (which = 0/1): the nonzero-weight columns are found
+// on the fly (no list, no barrier); this wavefront takes every second one, four at a time.
+template <int NCH>
+__device__ __forceinline__ int hb_partial(const double *__restrict__ V, int N, const double *w, int which,
+                                          double *stage) {
+    const int lane = threadIdx.x & 63;
+    double2 acc[NCH];
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) acc[m] = make_double2(0.0, 0.0);
+    int cj[4] = {0, 0, 0, 0};
+    int have = 0, seen = 0;
+    auto flush = [&](int n) {
+        const double *__restrict__ col[4];
+        double wj[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = (c < n) ? cj[c] : cj[0];
+            col[c] = V + (size_t)j * N;
+            wj[c] = (c < n) ? w[j] : 0.0;
+        }
+        double2 v[NCH][4];
+#pragma unroll
+        for (int m = 0; m < NCH; ++m) {
+            const int r = lane * 2 + 128 * m;
+            const int rr = (r < N) ? r : 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[m][c] = *reinterpret_cast<const double2 *>(col[c] + rr);
+        }
+#pragma unroll
+        for (int m = 0; m < NCH; ++m) {
+            const int r = lane * 2 + 128 * m;
+            const double keep = (r < N) ? 1.0 : 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double wk = wj[c] * keep;
+                acc[m].x = fma(v[m][c].x, wk, acc[m].x);
+                acc[m].y = fma(v[m][c].y, wk, acc[m].y);
+            }
+        }
+    };
+    for (int c0 = 0; c0 < N; c0 += 64) {
+        const int i = c0 + lane;
+        unsigned long long m = __ballot((i < N) && (w[i < N ? i : 0] != 0.0));
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if ((seen & 1) == which) {
+                if (have == 0) cj[0] = c0 + b;
+                else if (have == 1) cj[1] = c0 + b;
+                else if (have == 2) cj[2] = c0 + b;
+                else cj[3] = c0 + b;
+                have += 1;
+                if (have == 4) {
+                    flush(4);
+                    have = 0;
+                }
+            }
+            seen += 1;
+        }
+    }
+    if (have > 0) flush(have);
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        const int r = lane * 2 + 128 * m;
+        if (r < N) *reinterpret_cast<double2 *>(stage + (size_t)which * N + r) = acc[m];
+    }
+    return seen;
+}
+
+// lambda of the Schur system H lam = s (W <= 11), H symmetric (lower part given), one wavefront:
 // lane i holds row i of H and s_i; eliminations broadcast the pivot row with v_readlane.  Returns false
 // when a pivot is not > 0 (the reference's cholesky(C) throws).  On return lane w < W holds lam_w.
 __device__ __forceinline__ bool small_spd_solve(const double *H, const double *rhs_, int W, double &lam) {
@@ -1228,7 +1386,77 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     I.ord = L.ordl;
     I.fpos = L.fpos;
     I.RC = C.RC;
-    if (useInc) {
+    // wavefront-specialised front half (see inc_sync_w0): needs the AXPY loads (N even, N <= 512), a rank filter
+    // that fits in registers, and room in the scratch arena for two partial vectors plus X
+    bool frontDone = false;
+    int Wspec = W0;
+    if (useInc && VEC == 2 && W0 <= RF_ROWS && K + 1 <= 128 && (long)2 * N + (long)W0 * (K + 1) + 8 <= C.yOff) {
+        PHASE(C, 1);
+        double *X = ar + 2 * N;
+        for (int w = wave; w < W0; w += NW) {  // E-row sweep (SSQP.jl:290-295), rows over the wavefronts
+            const int r = L.rowsE[w];
+            const double *__restrict__ row = Ct + (size_t)r * N;
+            double acc = 0.0;
+#pragma unroll 4
+            for (int i = lane * 2; i < N; i += 128) {
+                const double2 v = *reinterpret_cast<const double2 *>(row + i);
+                const double2 zz = *reinterpret_cast<const double2 *>(L.zm + i);
+                const int p0 = L.pos[i], p1 = L.pos[i + 1];
+                acc = fma(v.y, zz.y, fma(v.x, zz.x, acc));
+                if (p0 >= 0) X[w + W0 * p0] = v.x;
+                if (p1 >= 0) X[w + W0 * p1] = v.y;
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) {
+                const double be = rhs[r] - acc;
+                L.bE[w] = be;
+                X[w + W0 * K] = be;
+            }
+        }
+        __syncthreads();
+        PHASE(C, 13);
+        if (wave == 0) {
+            int nApp = 0;
+            const int Kf = inc_sync_w0(I, C.Kfac, L, V, N, nApp);
+            if (lane == 0) {
+                L.ired[2 * NW + 10] = Kf;
+                L.ired[2 * NW + 11] = nApp;
+            }
+        } else if (wave == 1) {
+            int w = W0;
+            if (W0 > 0) w = (W0 <= 4) ? rank_filter_regs<4, 2>(X, W0, K + 1, tol, L) : rank_filter_wave(X, W0, K + 1, tol, L);
+            if (w < W0) {
+                const double v = (lane < w) ? L.bE[L.ra[lane < w ? lane : 0]] : 0.0;
+                wave_sync();
+                if (lane < w) L.bE[lane] = v;
+            } else if (lane < W0) {
+                L.ra[lane] = (int16_t)lane;
+            }
+            if (lane == 0) L.ired[2 * NW + 4] = w;
+        } else {
+            const int cnt = hb_partial<4>(V, N, L.zm, wave - 2, ar);
+            if (wave == 2 && lane == 0) L.ired[2 * NW + 12] = cnt;
+        }
+        __syncthreads();
+        PHASE(C, 3);
+        const int Kf = L.ired[2 * NW + 10];
+        C.Kfac = Kf;
+        if (Kf < 0) {  // cholesky(V[F,F]) of the reference would throw here
+            C.ret = -1;
+            C.det = SSQP_DETAIL_POSDEF_V;
+            return ACT_BREAK;
+        }
+        Wspec = L.ired[2 * NW + 4];
+        C.sRead += 64ll * L.ired[2 * NW + 11] * K + 8ll * N * L.ired[2 * NW + 12] - 8ll * N * K;
+        for (int i = tid; i < N; i += NT) L.gam[i] = ar[i] + ar[N + i];  // hB = sum of the two partial vectors
+        for (int e = tid; e < W0 * K; e += NT) {  // border right-hand sides AE' in factor order (X may be consumed
+            const int w = e / K, r = e - w * K;     //  by the rank filter: re-gather from the constraint rows)
+            I.Y[(size_t)w * I.RC + r] = Ct[(size_t)L.rowsE[w] * N + I.ord[r]];
+        }
+        __syncthreads();
+        frontDone = true;
+    }
+    if (useInc && !frontDone) {
         PHASE(C, 13);
         int Kf = C.Kfac;
         if (Kf < 0) {  // the factor was overwritten by a from-scratch pass: start over
@@ -1314,8 +1542,8 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     }
 
     // ---- E-row sweep: bE and X = [AE bE]   (SSQP.jl:290-295) ----
-    PHASE(C, 1);
-    {
+    if (!frontDone) PHASE(C, 1);
+    if (!frontDone) {
         double *X = ar;
         for (int w = wave; w < W0; w += NW) {
             const int r = L.rowsE[w];
@@ -1348,8 +1576,8 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             }
         }
     }
-    __syncthreads();
-    if (useInc) {  // border right-hand sides AE' in factor order (the rank filter is about to destroy X)
+    if (!frontDone) __syncthreads();
+    if (useInc && !frontDone) {  // border right-hand sides AE' in factor order (the rank filter is about to destroy X)
         for (int e = tid; e < W0 * K; e += NT) {
             const int w = e / K, r = e - w * K;
             I.Y[(size_t)w * I.RC + r] = ar[w + W0 * (int)L.pos[I.ord[r]]];
@@ -1357,9 +1585,9 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         __syncthreads();
     }
     // ---- rank filter  (SSQP.jl:310-319) ----
-    PHASE(C, 2);
-    int W = W0;
-    if (W0 > 0) {
+    if (!frontDone) PHASE(C, 2);
+    int W = frontDone ? Wspec : W0;
+    if (W0 > 0 && !frontDone) {
         if ((long)W0 * (K + 1) <= 4096) {  // small: one wavefront, no workgroup barriers
             if (wave == 0) {
                 SUBPHASE_DECL(trf);
@@ -1376,15 +1604,17 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             W = rank_filter(ar, W0, K + 1, tol, L);
         }
     }
-    if (W < W0) {
-        double v = 0.0;
-        if (tid < W) v = L.bE[L.ra[tid]];
+    if (!frontDone) {
+        if (W < W0) {
+            double v = 0.0;
+            if (tid < W) v = L.bE[L.ra[tid]];
+            __syncthreads();
+            if (tid < W) L.bE[tid] = v;
+        } else {
+            for (int w = tid; w < W0; w += NT) L.ra[w] = (int16_t)w;
+        }
         __syncthreads();
-        if (tid < W) L.bE[tid] = v;
-    } else {
-        for (int w = tid; w < W0; w += NT) L.ra[w] = (int16_t)w;
     }
-    __syncthreads();
 
     double *fac = ar;  // (from-scratch path: packed factor; least-squares scratch of KKTchk! in both paths)
     if (useInc) {
@@ -1392,11 +1622,11 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         PHASE(C, 3);
         C.pathBits |= 4;
         // c = V[B,F]'zB + q[F]: hB = V[:, nz(zB)] zB in AXPY form (only the bound variables that are not at 0)
-        {
+        if (!frontDone) {
             const int ncols = stream_matvec<VEC>(V, N, L.zm, C.dense, ar, L.gam, L);
             C.sRead += 8ll * N * ncols - 8ll * N * K;  // (the K term is added by the common accounting below)
+            __syncthreads();
         }
-        __syncthreads();
         for (int r = tid; r < K; r += NT) {
             const int i = I.ord[r];
             I.Y[(size_t)W0 * I.RC + r] = L.gam[i] + q[i];
@@ -1408,9 +1638,10 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         else inc_forward_border<2>(I, K, W + 1, L.perm);
         __syncthreads();
         PHASE(C, 5);
-        // Schur block: H = AE V^-1 AE' (W x W, lower) into the scratch arena, t = AE V^-1 c into tv
+        // Schur block: H = AE V^-1 AE' (W x W, lower) into the scratch arena, t = AE V^-1 c into tv.
+        // One thread per (a, b) pair walks the K rows: no cross-lane reduction, all pairs in parallel.
         double *H = ar;
-        for (int e = wave; e < W * (W + 1) / 2 + W; e += NW) {
+        for (int e = tid; e < W * (W + 1) / 2 + W; e += NT) {
             int a, b;
             if (e < W) {
                 a = W;
@@ -1426,15 +1657,13 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             }
             const double *Ya = I.Y + (size_t)L.perm[a] * I.RC, *Yb = I.Y + (size_t)L.perm[b] * I.RC;
             double acc = 0.0;
-            for (int r = lane; r < K; r += 64) acc = fma(Ya[r] * I.rdv[r], Yb[r], acc);
-            acc = wave_sum(acc);
-            if (lane == 0) {
-                if (e < W) L.tv[b] = acc;
-                else H[a + W * b] = acc;
-            }
+#pragma unroll 4
+            for (int r = 0; r < K; ++r) acc = fma(Ya[r] * I.rdv[r], Yb[r], acc);
+            if (e < W) L.tv[b] = acc;
+            else H[a + W * b] = acc;
         }
         __syncthreads();
-        if (wave == 0) {  // lambda: H lam = bE + t, alphaL = -lam; W <= 7, in registers
+        if (wave == 0) {  // lambda: H lam = bE + t, alphaL = -lam; W <= 11, in registers
             if (lane < W) L.tv[lane] = L.bE[lane] + L.tv[lane];
             wave_sync();
             double lam;
