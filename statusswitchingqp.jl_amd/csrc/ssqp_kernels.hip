@@ -363,9 +363,17 @@ __device__ __forceinline__ void stream_cols(const double *__restrict__ V, int N,
 // add exact zeros), which is what makes the gamma pass cheap on portfolio problems where most bound
 // variables sit at d = 0.  The NW per-wave partial vectors are summed in wave order through `stage`
 // (NW*N doubles), so the result is deterministic.  N even (16-byte loads), N <= 128*NCH.
+// Extra "columns" the AXPY pass can take after the columns of V (list entries N.., see stream_matvec): the kept
+// constraint rows with weights alphaL (the AB'*alphaL term of gamma, SSQP.jl:352) and q with weight 1.
+struct AxpyExt {
+    const double *Ct, *q, *aL;
+    const int16_t *rowsE, *ra;
+    int W;  // -1: no extras
+};
+
 template <int NCH, int NCOL>
 __device__ __forceinline__ void stream_axpy(const double *__restrict__ V, int N, const int16_t *nzl, int nnz,
-                                            const double *w, double *stage, double *out) {
+                                            const double *w, double *stage, double *out, const AxpyExt &X_) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double2 acc[NCH];
 #pragma unroll
@@ -377,8 +385,16 @@ __device__ __forceinline__ void stream_axpy(const double *__restrict__ V, int N,
         for (int c = 0; c < NCOL; ++c) {
             const bool live = (t + c < nnz);
             const int j = nzl[live ? t + c : t];
-            col[c] = V + (size_t)j * N;
-            wj[c] = live ? w[j] : 0.0;
+            if (j < N) {
+                col[c] = V + (size_t)j * N;
+                wj[c] = live ? w[j] : 0.0;
+            } else if (j < N + X_.W) {
+                col[c] = X_.Ct + (size_t)X_.rowsE[X_.ra[j - N]] * N;
+                wj[c] = live ? X_.aL[j - N] : 0.0;
+            } else {
+                col[c] = X_.q;
+                wj[c] = live ? 1.0 : 0.0;
+            }
         }
         // all NCOL*NCH loads are issued before the first use: rows beyond N are read from row 0 and dropped
         double2 v[NCH][NCOL];
@@ -482,13 +498,19 @@ __device__ __forceinline__ int compact_nonzero(const double *w, int N, bool dens
 // out = V * w restricted to the columns with nonzero weight: AXPY form for even N, dot form otherwise
 template <int VEC>
 __device__ __forceinline__ int stream_matvec(const double *__restrict__ V, int N, const double *w, bool dense,
-                                             double *stage, double *out, const Lds &L) {
+                                             double *stage, double *out, const Lds &L,
+                                             const AxpyExt &X_ = AxpyExt{nullptr, nullptr, nullptr, nullptr, nullptr, -1}) {
     // VEC: 1 scalar loads (odd N); 2, 3, 4: 16-byte loads with N <= 512, 1024, 2048 (register slots per lane)
     if (VEC >= 2) {
-        const int nnz = compact_nonzero(w, N, dense, L.perm, L);
-        if (VEC == 2) stream_axpy<4, 4>(V, N, L.perm, nnz, w, stage, out);
-        else if (VEC == 3) stream_axpy<8, 2>(V, N, L.perm, nnz, w, stage, out);
-        else stream_axpy<16, 1>(V, N, L.perm, nnz, w, stage, out);
+        int nnz = compact_nonzero(w, N, dense, L.perm, L);
+        if (X_.W >= 0) {  // append the constraint rows and q to the column list
+            if ((int)threadIdx.x <= X_.W) L.perm[nnz + threadIdx.x] = (int16_t)(N + threadIdx.x);
+            nnz += X_.W + 1;
+            __syncthreads();
+        }
+        if (VEC == 2) stream_axpy<4, 4>(V, N, L.perm, nnz, w, stage, out, X_);
+        else if (VEC == 3) stream_axpy<8, 2>(V, N, L.perm, nnz, w, stage, out, X_);
+        else stream_axpy<16, 1>(V, N, L.perm, nnz, w, stage, out, X_);
         return nnz;
     } else {
         stream_cols<VEC>(V, N, nullptr, 1, N, w, out);
@@ -1909,7 +1931,9 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         // per-wave partial vectors go through the LDS arena when it has room (the factor is dead), else
         // through the workgroup's global arena
         double *stage = (INLDS && (long)NW * N <= C.arenaCap) ? ar : C.garena;
-        const int ncols = stream_matvec<VEC>(V, N, L.zm, C.dense, stage, L.gam, L);
+        // (even N: the constraint-row term AB'*alphaL and q ride along as extra AXPY columns)
+        const AxpyExt ext{Ct, q, L.aL, L.rowsE, L.ra, W};
+        const int ncols = stream_matvec<VEC>(V, N, L.zm, C.dense, stage, L.gam, L, ext);
         C.sRead += 8ll * N * ncols;
     }
     __syncthreads();
@@ -1921,11 +1945,13 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     KeyMin ev{inf, 0x7fffffff};
     for (int i = tid; i < N; i += NT) {
         if (L.pos[i] >= 0) continue;
-        double gmm = L.gam[i] + q[i];
-        double s3 = 0.0;
+        double gmm = L.gam[i];
+        if (VEC == 1) {  // odd N: the dot-form pass leaves q and AB'*alphaL to be added here
+            double s3 = 0.0;
 #pragma unroll 4
-        for (int w = 0; w < W; ++w) s3 = fma(Ct[(size_t)L.rowsE[L.ra[w]] * N + i], L.aL[w], s3);
-        gmm += s3;
+            for (int w = 0; w < W; ++w) s3 = fma(Ct[(size_t)L.rowsE[L.ra[w]] * N + i], L.aL[w], s3);
+            gmm = (gmm + q[i]) + s3;
+        }
         const int s = L.S[i];
         if (s == SSQP_UP && gmm > tolG) ev = keymin(ev, KeyMin{-gmm, i});
         else if (s == SSQP_DN && gmm < -tolG) ev = keymin(ev, KeyMin{gmm, i});
