@@ -101,23 +101,37 @@ constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
 constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7-i inside each 8 lanes
 constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15-i inside each 16 lanes
 
+// cross-row steps of a 64-lane reduction without the LDS: row_bcast15 (into rows 1 and 3) and row_bcast31 (into
+// rows 2 and 3) leave the result in lane 63; v_readlane hands it to every lane as a wavefront-uniform value
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64_rows(double v, double oldv) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(oldv), lo, CTRL, ROWMASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(oldv), hi, CTRL, ROWMASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bcast63_f64(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
     v += dpp_f64<DPP_XOR1>(v);
     v += dpp_f64<DPP_XOR2>(v);
     v += dpp_f64<DPP_HALF_MIRROR>(v);
     v += dpp_f64<DPP_MIRROR>(v);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    v += dpp_f64_rows<0x142, 0xA>(v, 0.0);   // rows 1,3 += row 0,2 totals (other rows add 0)
+    v += dpp_f64_rows<0x143, 0xC>(v, 0.0);   // rows 2,3 += total of rows 0-1
+    return bcast63_f64(v);
 }
 __device__ __forceinline__ double wave_max(double v) {
     v = fmax(v, dpp_f64<DPP_XOR1>(v));
     v = fmax(v, dpp_f64<DPP_XOR2>(v));
     v = fmax(v, dpp_f64<DPP_HALF_MIRROR>(v));
     v = fmax(v, dpp_f64<DPP_MIRROR>(v));
-    v = fmax(v, __shfl_xor(v, 16, 64));
-    v = fmax(v, __shfl_xor(v, 32, 64));
-    return v;
+    v = fmax(v, dpp_f64_rows<0x142, 0xA>(v, v));
+    v = fmax(v, dpp_f64_rows<0x143, 0xC>(v, v));
+    return bcast63_f64(v);
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int srcLane) {
@@ -125,6 +139,8 @@ __device__ __forceinline__ double readlane_f64(double v, int srcLane) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
     return __hiloint2double(hi, lo);
 }
+
+__device__ __forceinline__ double wave_max_uniform(double v) { return wave_max(v); }
 
 struct KeyMin {  // minimum value, ties -> smallest order
     double v;
@@ -140,19 +156,24 @@ __device__ __forceinline__ KeyMin keymin_dpp(KeyMin a) {
     b.ord = dpp_i32<CTRL>(a.ord);
     return keymin(a, b);
 }
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ KeyMin keymin_rows(KeyMin a) {
+    KeyMin b;
+    b.v = dpp_f64_rows<CTRL, ROWMASK>(a.v, a.v);
+    b.ord = __builtin_amdgcn_update_dpp(a.ord, a.ord, CTRL, ROWMASK, 0xF, false);
+    return keymin(a, b);
+}
 __device__ __forceinline__ KeyMin wave_keymin(KeyMin a) {
     a = keymin_dpp<DPP_XOR1>(a);
     a = keymin_dpp<DPP_XOR2>(a);
     a = keymin_dpp<DPP_HALF_MIRROR>(a);
     a = keymin_dpp<DPP_MIRROR>(a);
-#pragma unroll
-    for (int o = 16; o <= 32; o <<= 1) {
-        KeyMin b;
-        b.v = __shfl_xor(a.v, o, 64);
-        b.ord = __shfl_xor(a.ord, o, 64);
-        a = keymin(a, b);
-    }
-    return a;
+    a = keymin_rows<0x142, 0xA>(a);
+    a = keymin_rows<0x143, 0xC>(a);
+    KeyMin r;
+    r.v = bcast63_f64(a.v);
+    r.ord = __builtin_amdgcn_readlane(a.ord, 63);
+    return r;
 }
 
 struct Lds {
@@ -587,17 +608,24 @@ __device__ __forceinline__ int rank_filter_wave(double *X, int W0, int nc, doubl
     wave_sync();
     int i = 0, j = 0, nrows = 0;
     while (i < W0 && j < nc) {
-        KeyMin best{1.0, 0x7fffffff};  // maximise |x| == minimise -|x|; 1.0 never wins
-        for (int t = j + lane; t < nc; t += 64) {
-            const double v = -fabs(X[i + W0 * (int)L.perm[t]]);
-            best = keymin(best, KeyMin{v, t});
+        // first maximum of |X[i, c0[j:nc]]| in c0 order: positions t = j + lane (+64..) are visited in order, so it
+        // is the lowest lane of the earliest 64-chunk that holds the maximum
+        double a0 = -1.0, a1 = -1.0, a2 = -1.0;
+        {
+            const int t0 = j + lane, t1 = t0 + 64, t2 = t0 + 128;
+            if (t0 < nc) a0 = fabs(X[i + W0 * (int)L.perm[t0]]);
+            if (t1 < nc) a1 = fabs(X[i + W0 * (int)L.perm[t1]]);
+            if (t2 < nc) a2 = fabs(X[i + W0 * (int)L.perm[t2]]);
         }
-        best = wave_keymin(best);
-        const double m = -best.v;
-        const int mj = best.ord;
+        const double m = wave_max_uniform(fmax(a0, fmax(a1, a2)));
         if (!(m > tol)) {
             i += 1;
             continue;
+        }
+        int mj;
+        {
+            const unsigned long long e0 = __ballot(a0 == m), e1 = __ballot(a1 == m), e2 = __ballot(a2 == m);
+            mj = j + (e0 ? (__ffsll((long long)e0) - 1) : (e1 ? 64 + (__ffsll((long long)e1) - 1) : 128 + (__ffsll((long long)e2) - 1)));
         }
         if (lane == 0) {
             L.ra[nrows] = (int16_t)i;
@@ -1438,12 +1466,14 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         __syncthreads();
         PHASE(C, 13);
         if (wave == 0) {
+            SUBPHASE_DECL(tw0);
             int nApp = 0;
             const int Kf = inc_sync_w0(I, C.Kfac, L, V, N, nApp);
             if (lane == 0) {
                 L.ired[2 * NW + 10] = Kf;
                 L.ired[2 * NW + 11] = nApp;
             }
+            SUBPHASE(14, tw0);
         } else if (wave == 1) {
             int w = W0;
             if (W0 > 0) w = (W0 <= 4) ? rank_filter_regs<4, 2>(X, W0, K + 1, tol, L) : rank_filter_wave(X, W0, K + 1, tol, L);
@@ -1610,7 +1640,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     if (!frontDone) PHASE(C, 2);
     int W = frontDone ? Wspec : W0;
     if (W0 > 0 && !frontDone) {
-        if ((long)W0 * (K + 1) <= 4096) {  // small: one wavefront, no workgroup barriers
+        if ((long)W0 * (K + 1) <= 4096 && K + 1 <= 64 * RF_CS) {  // small: one wavefront, no workgroup barriers
             if (wave == 0) {
                 SUBPHASE_DECL(trf);
                 int w;
