@@ -103,6 +103,10 @@ inline size_t global_arena_doubles(int N, int M, int J) {
     const size_t ls = K * W0 + W0 * W0 + W0;
     size_t f = (packed + R > ls ? packed + R : ls) + 64;
     if (f < (size_t)NW * N + 64) f = (size_t)NW * N + 64;   // staging of the AXPY partial vectors
+    // kept-factor engine in the global arena: staging in front, then Y (12 columns), 1/d, factor for up to 256 rows
+    const size_t rcg = N < 256 ? N : 256;
+    const size_t eng = (size_t)NW * N + 64 + 13 * rcg + rcg * (rcg + 1) / 2 + 64;
+    if (f < eng) f = eng;
     return (x > f ? x : f) + 64;
 }
 

@@ -946,7 +946,7 @@ __device__ __forceinline__ void back_substitute(const double *fac, const double 
 // lane r&63 of register slot r>>6 (two slots: K <= 128).
 // =====================================================================================================
 constexpr int INC_RBM = 12;   // border right-hand sides the engine carries (W + 1 <= 12)
-constexpr int INC_KMAX = 128; // two register slots of 64 rows
+constexpr int INC_KMAX = 256; // up to four register slots of 64 rows
 
 struct Inc {
     double *fcol, *rdv, *Y;  // factor, reciprocal pivots, border right-hand sides (RC per column)
@@ -957,37 +957,56 @@ __device__ __forceinline__ int cofs(int c, int RC) { return c * RC - ((c * (c - 
 
 // value of row r (uniform) from the register slots
 template <int SL>
-__device__ __forceinline__ double row_bcast(double s0, double s1, int r) {
-    if (SL == 1) return readlane_f64(s0, r);
-    return (r < 64) ? readlane_f64(s0, r) : readlane_f64(s1, r - 64);
+__device__ __forceinline__ double row_bcast(const double (&sl)[SL], int r) {
+    if (SL == 1) return readlane_f64(sl[0], r);
+    const int t = r >> 6, l = r & 63;
+    if (t == 0) return readlane_f64(sl[0], l);
+    if (SL == 2 || t == 1) return readlane_f64(sl[1], l);
+    if (t == 2) return readlane_f64(sl[SL > 2 ? 2 : 0], l);
+    return readlane_f64(sl[SL > 3 ? 3 : 0], l);
 }
 
-// SL = register slots in use: 1 when K <= 64 (the common case: half the work, no slot selection), else 2.
+// SL = register slots in use: 1 when K <= 64 (the common case), 2 up to 128, 4 up to 256.  The factor pointers
+// may be LDS (K up to RC rows fit the arena) or the workgroup's global arena (larger K); the code is the same.
 
-// Append variable j as row K (wavefront 0 only).  Returns false when the new pivot is not > 0.
+// Append variable j as row K (one wavefront).  Returns false when the new pivot is not > 0.
 template <int SL>
 __device__ __forceinline__ bool inc_append(const Inc &I, int K, int j, const double *__restrict__ V, int N) {
     const int lane = threadIdx.x & 63;
     const int RC = I.RC;
     const double *__restrict__ col = V + (size_t)j * N;
-    const int r0 = lane, r1 = lane + 64;
     const double vjj = col[j];
-    double y0 = (r0 < K) ? col[I.ord[r0 < K ? r0 : 0]] : 0.0;
-    double y1 = (SL == 2 && r1 < K) ? col[I.ord[r1 < K ? r1 : 0]] : 0.0;
+    double y[SL];
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int r = lane + 64 * t;
+        y[t] = (r < K) ? col[I.ord[r < K ? r : 0]] : 0.0;
+    }
 #pragma unroll 4
     for (int c = 0; c < K; ++c) {
         const int oc = cofs(c, RC) - c;
-        const double l0 = I.fcol[oc + ((r0 > c && r0 < K) ? r0 : c)];
-        const double l1 = (SL == 2) ? I.fcol[oc + ((r1 > c && r1 < K) ? r1 : c)] : 0.0;
-        const double yc = row_bcast<SL>(y0, y1, c);
-        y0 = (r0 > c && r0 < K) ? fma(-l0, yc, y0) : y0;
-        if (SL == 2) y1 = (r1 > c && r1 < K) ? fma(-l1, yc, y1) : y1;
+        double l[SL];
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + 64 * t;
+            l[t] = I.fcol[oc + ((r > c && r < K) ? r : c)];
+        }
+        const double yc = row_bcast<SL>(y, c);
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + 64 * t;
+            y[t] = (r > c && r < K) ? fma(-l[t], yc, y[t]) : y[t];
+        }
     }
-    const double t0 = (r0 < K) ? y0 * I.rdv[r0 < K ? r0 : 0] : 0.0;
-    const double t1 = (SL == 2 && r1 < K) ? y1 * I.rdv[r1 < K ? r1 : 0] : 0.0;
-    const double dnew = vjj - wave_sum(fma(y0, t0, y1 * t1));
-    if (r0 < K) I.fcol[cofs(r0, RC) + K - r0] = t0;
-    if (SL == 2 && r1 < K) I.fcol[cofs(r1, RC) + K - r1] = t1;
+    double part = 0.0;
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int r = lane + 64 * t;
+        const double tr = (r < K) ? y[t] * I.rdv[r < K ? r : 0] : 0.0;
+        part = fma(y[t], tr, part);
+        if (r < K) I.fcol[cofs(r, RC) + K - r] = tr;
+    }
+    const double dnew = vjj - wave_sum(part);
     if (lane == 0) {
         I.fcol[cofs(K, RC)] = dnew;
         I.rdv[K] = fast_rcp(dnew);
@@ -998,211 +1017,234 @@ __device__ __forceinline__ bool inc_append(const Inc &I, int K, int j, const dou
     return dnew > 0.0;
 }
 
-// Rank-1 part of deleting row p: L33 D3 L33' += d_p l l'  (wavefront 0 only).
+// Rank-1 part of deleting row p: L33 D3 L33' += d_p l l'  (one wavefront).
 template <int SL>
 __device__ __forceinline__ void inc_delete_update(const Inc &I, int K, int p) {
     const int lane = threadIdx.x & 63;
     const int RC = I.RC;
-    const int r0 = lane, r1 = lane + 64;
-    double d0 = (r0 < K) ? I.fcol[cofs(r0 < K ? r0 : 0, RC)] : 1.0;
-    double d1 = (SL == 2 && r1 < K) ? I.fcol[cofs(r1 < K ? r1 : 0, RC)] : 1.0;
     const int op = cofs(p, RC) - p;
-    double w0 = (r0 > p && r0 < K) ? I.fcol[op + r0] : 0.0;
-    double w1 = (SL == 2 && r1 > p && r1 < K) ? I.fcol[op + r1] : 0.0;
-    double alpha = row_bcast<SL>(d0, d1, p);
+    double d[SL], w[SL];
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int r = lane + 64 * t;
+        d[t] = (r < K) ? I.fcol[cofs(r < K ? r : 0, RC)] : 1.0;
+        w[t] = (r > p && r < K) ? I.fcol[op + r] : 0.0;
+    }
+    double alpha = row_bcast<SL>(d, p);
     for (int k = p + 1; k < K; ++k) {
         const int ok = cofs(k, RC) - k;
-        double l0 = I.fcol[ok + ((r0 > k && r0 < K) ? r0 : k)];
-        double l1 = (SL == 2) ? I.fcol[ok + ((r1 > k && r1 < K) ? r1 : k)] : 0.0;
-        const double pk = row_bcast<SL>(w0, w1, k);
-        const double dk = row_bcast<SL>(d0, d1, k);
+        double l[SL];
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + 64 * t;
+            l[t] = I.fcol[ok + ((r > k && r < K) ? r : k)];
+        }
+        const double pk = row_bcast<SL>(w, k);
+        const double dk = row_bcast<SL>(d, k);
         const double dn = fma(alpha * pk, pk, dk);
         const double rdn = fast_rcp(dn);
         const double beta = pk * alpha * rdn;
         alpha = alpha * dk * rdn;
-        if (r0 == k) d0 = dn;
-        if (SL == 2 && r1 == k) d1 = dn;
-        if (r0 > k && r0 < K) {
-            w0 = fma(-pk, l0, w0);
-            l0 = fma(beta, w0, l0);
-            I.fcol[ok + r0] = l0;
-        }
-        if (SL == 2 && r1 > k && r1 < K) {
-            w1 = fma(-pk, l1, w1);
-            l1 = fma(beta, w1, l1);
-            I.fcol[ok + r1] = l1;
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + 64 * t;
+            if (r == k) d[t] = dn;
+            if (r > k && r < K) {
+                w[t] = fma(-pk, l[t], w[t]);
+                I.fcol[ok + r] = fma(beta, w[t], l[t]);
+            }
         }
     }
-    if (r0 > p && r0 < K) {
-        I.fcol[cofs(r0, RC)] = d0;
-        I.rdv[r0] = fast_rcp(d0);
-    }
-    if (SL == 2 && r1 > p && r1 < K) {
-        I.fcol[cofs(r1, RC)] = d1;
-        I.rdv[r1] = fast_rcp(d1);
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int r = lane + 64 * t;
+        if (r > p && r < K) {
+            I.fcol[cofs(r, RC)] = d[t];
+            I.rdv[r] = fast_rcp(d[t]);
+        }
     }
     wave_sync();
 }
 
-// Physically remove row/column p (all wavefronts; contains workgroup barriers, call uniformly).
+// Physically remove row/column p (one wavefront, no workgroup barrier).
+template <int SL>
 __device__ __forceinline__ void inc_delete_compact(const Inc &I, int K, int p) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int RC = I.RC;
-    const int r0 = lane, r1 = lane + 64;
-    // (A) columns c < p lose row p: rows r > p move up by one inside the column
-    for (int c = wave; c < p; c += NW) {
+    for (int c = 0; c < p; ++c) {  // (A) columns c < p lose row p: rows r > p move up by one inside the column
         const int oc = cofs(c, RC) - c;
-        const double a0 = (r0 > p && r0 < K) ? I.fcol[oc + r0] : 0.0;
-        const double a1 = (r1 > p && r1 < K) ? I.fcol[oc + r1] : 0.0;
+        double a[SL];
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + 64 * t;
+            a[t] = (r > p && r < K) ? I.fcol[oc + r] : 0.0;
+        }
         wave_sync();
-        if (r0 > p && r0 < K) I.fcol[oc + r0 - 1] = a0;
-        if (r1 > p && r1 < K) I.fcol[oc + r1 - 1] = a1;
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + 64 * t;
+            if (r > p && r < K) I.fcol[oc + r - 1] = a[t];
+        }
     }
-    // bookkeeping of rows > p (one wavefront: read everything, then write)
-    if (wave == NW - 1) {
-        const double q0 = (r0 > p && r0 < K) ? I.rdv[r0] : 0.0, q1 = (r1 > p && r1 < K) ? I.rdv[r1] : 0.0;
-        const int v0 = (r0 > p && r0 < K) ? I.ord[r0] : 0, v1 = (r1 > p && r1 < K) ? I.ord[r1] : 0;
+    {  // bookkeeping of rows > p: read everything, then write
+        double qv[SL];
+        int vv[SL];
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + 64 * t;
+            const bool m = r > p && r < K;
+            qv[t] = m ? I.rdv[r] : 0.0;
+            vv[t] = m ? I.ord[r] : 0;
+        }
         const int vdel = I.ord[p];
         wave_sync();
         if (lane == 0) I.fpos[vdel] = -1;
-        if (r0 > p && r0 < K) {
-            I.rdv[r0 - 1] = q0;
-            I.ord[r0 - 1] = (int16_t)v0;
-            I.fpos[v0] = (int16_t)(r0 - 1);
-        }
-        if (r1 > p && r1 < K) {
-            I.rdv[r1 - 1] = q1;
-            I.ord[r1 - 1] = (int16_t)v1;
-            I.fpos[v1] = (int16_t)(r1 - 1);
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + 64 * t;
+            if (r > p && r < K) {
+                I.rdv[r - 1] = qv[t];
+                I.ord[r - 1] = (int16_t)vv[t];
+                I.fpos[vv[t]] = (int16_t)(r - 1);
+            }
         }
     }
-    // (B) columns c > p become columns c-1 (rows shift up too): rounds of NW columns, read - barrier - write
-    for (int c0 = p + 1; c0 < K; c0 += NW) {
-        const int c = c0 + wave;
-        const bool live = c < K;
-        const int oc = cofs(live ? c : p + 1, RC) - (live ? c : p + 1);
-        const double a0 = (live && r0 >= c && r0 < K) ? I.fcol[oc + r0] : 0.0;
-        const double a1 = (live && r1 >= c && r1 < K) ? I.fcol[oc + r1] : 0.0;
-        __syncthreads();
-        if (live) {
-            const int on = cofs(c - 1, RC) - (c - 1);
-            if (r0 >= c && r0 < K) I.fcol[on + r0 - 1] = a0;
-            if (r1 >= c && r1 < K) I.fcol[on + r1 - 1] = a1;
+    for (int c = p + 1; c < K; ++c) {  // (B) column c -> c-1, ascending: the target was vacated one step earlier
+        const int oc = cofs(c, RC) - c, on = cofs(c - 1, RC) - (c - 1);
+        double a[SL];
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + 64 * t;
+            a[t] = (r >= c && r < K) ? I.fcol[oc + r] : 0.0;
         }
-        __syncthreads();
+        wave_sync();
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + 64 * t;
+            if (r >= c && r < K) I.fcol[on + r - 1] = a[t];
+        }
     }
-    __syncthreads();
+    wave_sync();
 }
 
-// Forward substitution L y = b for the border right-hand sides, in place in I.Y.  Right-hand side k of the
-// list (physical column phys[k] of Y) is taken by wavefront k & (NW-1): no exchange between wavefronts.
+// Forward substitution L y = b for the border right-hand sides, in place in I.Y.  Right-hand sides are taken two
+// at a time by the wavefronts (k, k+NW by wavefront k & (NW-1)): no exchange between wavefronts.
 template <int SL>
 __device__ __forceinline__ void inc_forward_border(const Inc &I, int K, int nrhs, const int16_t *phys) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int RC = I.RC;
-    const int r0 = lane, r1 = lane + 64;
     for (int b0 = wave; b0 < nrhs; b0 += 2 * NW) {
         const int b1 = b0 + NW;
         const bool two = b1 < nrhs;
         double *Y0 = I.Y + (size_t)phys[b0] * RC;
         double *Y1 = I.Y + (size_t)phys[two ? b1 : b0] * RC;
-        double y00 = (r0 < K) ? Y0[r0] : 0.0, y01 = (SL == 2 && r1 < K) ? Y0[r1] : 0.0;
-        double y10 = (r0 < K) ? Y1[r0] : 0.0, y11 = (SL == 2 && r1 < K) ? Y1[r1] : 0.0;
+        double ya[SL], yb[SL];
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + 64 * t;
+            ya[t] = (r < K) ? Y0[r] : 0.0;
+            yb[t] = (r < K) ? Y1[r] : 0.0;
+        }
 #pragma unroll 4
         for (int c = 0; c < K; ++c) {
             const int oc = cofs(c, RC) - c;
-            const double l0 = I.fcol[oc + ((r0 > c && r0 < K) ? r0 : c)];
-            const double l1 = (SL == 2) ? I.fcol[oc + ((r1 > c && r1 < K) ? r1 : c)] : 0.0;
-            const double ya = row_bcast<SL>(y00, y01, c);
-            const double yb = row_bcast<SL>(y10, y11, c);
-            const bool u0 = r0 > c && r0 < K;
-            y00 = u0 ? fma(-l0, ya, y00) : y00;
-            y10 = u0 ? fma(-l0, yb, y10) : y10;
-            if (SL == 2) {
-                const bool u1 = r1 > c && r1 < K;
-                y01 = u1 ? fma(-l1, ya, y01) : y01;
-                y11 = u1 ? fma(-l1, yb, y11) : y11;
+            double l[SL];
+#pragma unroll
+            for (int t = 0; t < SL; ++t) {
+                const int r = lane + 64 * t;
+                l[t] = I.fcol[oc + ((r > c && r < K) ? r : c)];
+            }
+            const double ca = row_bcast<SL>(ya, c);
+            const double cb = row_bcast<SL>(yb, c);
+#pragma unroll
+            for (int t = 0; t < SL; ++t) {
+                const int r = lane + 64 * t;
+                const bool u = r > c && r < K;
+                ya[t] = u ? fma(-l[t], ca, ya[t]) : ya[t];
+                yb[t] = u ? fma(-l[t], cb, yb[t]) : yb[t];
             }
         }
-        if (r0 < K) Y0[r0] = y00;
-        if (SL == 2 && r1 < K) Y0[r1] = y01;
-        if (two) {
-            if (r0 < K) Y1[r0] = y10;
-            if (SL == 2 && r1 < K) Y1[r1] = y11;
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + 64 * t;
+            if (r < K) Y0[r] = ya[t];
+            if (two && r < K) Y1[r] = yb[t];
         }
     }
 }
 
-// Back substitution L' x = v (unit upper), v in the register slots, wavefront 0 only.
+// Back substitution L' x = v (unit upper), v in the register slots, one wavefront.
 template <int SL>
-__device__ __forceinline__ void inc_backward(const Inc &I, int K, double &v0, double &v1) {
+__device__ __forceinline__ void inc_backward(const Inc &I, int K, double (&v)[SL]) {
     const int lane = threadIdx.x & 63;
     const int RC = I.RC;
-    const int c0 = lane, c1 = lane + 64;
-    const int o0 = cofs(c0 < K ? c0 : 0, RC) - (c0 < K ? c0 : 0);
-    const int o1 = cofs(c1 < K ? c1 : 0, RC) - (c1 < K ? c1 : 0);
+    int o[SL];
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int c = lane + 64 * t;
+        o[t] = cofs(c < K ? c : 0, RC) - (c < K ? c : 0);
+    }
 #pragma unroll 4
     for (int r = K - 1; r > 0; --r) {
-        const double l0 = I.fcol[o0 + (c0 < r ? r : (c0 < K ? c0 : 0))];  // L(r, c0): row r of column c0
-        const double l1 = (SL == 2) ? I.fcol[o1 + (c1 < r ? r : (c1 < K ? c1 : 0))] : 0.0;
-        const double xr = row_bcast<SL>(v0, v1, r);
-        v0 = (c0 < r) ? fma(-l0, xr, v0) : v0;
-        if (SL == 2) v1 = (c1 < r) ? fma(-l1, xr, v1) : v1;
+        double l[SL];
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int c = lane + 64 * t;
+            l[t] = I.fcol[o[t] + (c < r ? r : (c < K ? c : 0))];  // L(r, c): row r of column c
+        }
+        const double xr = row_bcast<SL>(v, r);
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int c = lane + 64 * t;
+            v[t] = (c < r) ? fma(-l[t], xr, v[t]) : v[t];
+        }
     }
 }
 
-
-// ---------------------------------------------------------------------------------------------------
-// Wavefront-specialised front half of a pass.  Factor sync, E-row sweep + rank filter and the hB stream are
-// independent of each other, and each is a chain a single wavefront walks; run as three concurrent chains
-// (wavefront 0 / wavefront 1 / wavefronts 2-3) they cost the longest one instead of the sum.  No workgroup
-// barrier may be used inside any of the three (the wavefronts are on different code paths).
-// ---------------------------------------------------------------------------------------------------
-
-// single-wavefront version of inc_delete_compact (wavefront 0)
-__device__ __forceinline__ void inc_delete_compact_w0(const Inc &I, int K, int p) {
+// v = D^-1 (Y_A alphaL + y_c), alpha = -L'^-1 v, scattered to gam (one wavefront)
+template <int SL>
+__device__ __forceinline__ void inc_alpha(const Inc &I, int K, int W, int W0, const int16_t *phys, const double *aL,
+                                          double *gam) {
     const int lane = threadIdx.x & 63;
-    const int RC = I.RC;
-    const int r0 = lane, r1 = lane + 64;
-    const bool m0 = r0 > p && r0 < K, m1 = r1 > p && r1 < K;
-    for (int c = 0; c < p; ++c) {  // (A) columns c < p lose row p
-        const int oc = cofs(c, RC) - c;
-        const double a0 = m0 ? I.fcol[oc + r0] : 0.0;
-        const double a1 = m1 ? I.fcol[oc + r1] : 0.0;
-        wave_sync();
-        if (m0) I.fcol[oc + r0 - 1] = a0;
-        if (m1) I.fcol[oc + r1 - 1] = a1;
+    const double *Yc = I.Y + (size_t)W0 * I.RC;
+    double v[SL];
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int r = lane + 64 * t;
+        v[t] = (r < K) ? Yc[r] : 0.0;
     }
-    {
-        const double q0 = m0 ? I.rdv[r0] : 0.0, q1 = m1 ? I.rdv[r1] : 0.0;
-        const int v0 = m0 ? I.ord[r0] : 0, v1 = m1 ? I.ord[r1] : 0;
-        const int vdel = I.ord[p];
-        wave_sync();
-        if (lane == 0) I.fpos[vdel] = -1;
-        if (m0) {
-            I.rdv[r0 - 1] = q0;
-            I.ord[r0 - 1] = (int16_t)v0;
-            I.fpos[v0] = (int16_t)(r0 - 1);
-        }
-        if (m1) {
-            I.rdv[r1 - 1] = q1;
-            I.ord[r1 - 1] = (int16_t)v1;
-            I.fpos[v1] = (int16_t)(r1 - 1);
+    for (int w = 0; w < W; ++w) {
+        const double *Yw = I.Y + (size_t)phys[w] * I.RC;
+        const double aw = aL[w];
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + 64 * t;
+            if (r < K) v[t] = fma(Yw[r], aw, v[t]);
         }
     }
-    for (int c = p + 1; c < K; ++c) {  // (B) column c -> c-1, ascending: the target was vacated one step earlier
-        const int oc = cofs(c, RC) - c, on = cofs(c - 1, RC) - (c - 1);
-        const bool n0 = r0 >= c && r0 < K, n1 = r1 >= c && r1 < K;
-        const double a0 = n0 ? I.fcol[oc + r0] : 0.0;
-        const double a1 = n1 ? I.fcol[oc + r1] : 0.0;
-        wave_sync();
-        if (n0) I.fcol[on + r0 - 1] = a0;
-        if (n1) I.fcol[on + r1 - 1] = a1;
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int r = lane + 64 * t;
+        v[t] *= (r < K) ? I.rdv[r] : 0.0;
     }
-    wave_sync();
+    inc_backward<SL>(I, K, v);
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int r = lane + 64 * t;
+        if (r < K) gam[I.ord[r]] = -v[t];
+    }
 }
 
-// factor sync by wavefront 0 alone.  Returns the new row count, or -1 when an appended pivot is not > 0.
+// dispatch on the number of register slots the current K needs
+#define INC_BY_SLOTS(K_, CALL1, CALL2, CALL4) \
+    do {                                      \
+        if ((K_) <= 64) { CALL1; }            \
+        else if ((K_) <= 128) { CALL2; }      \
+        else { CALL4; }                       \
+    } while (0)
+
+// factor sync by ONE wavefront: delete the rows whose variable left F (highest row first), append the new free
+// variables by increasing index.  Returns the new row count, or -1 when an appended pivot is not > 0.
 __device__ __forceinline__ int inc_sync_w0(const Inc &I, int Kf, const Lds &L, const double *__restrict__ V, int N,
                                            int &nAppended) {
     const int lane = threadIdx.x & 63;
@@ -1212,23 +1254,17 @@ __device__ __forceinline__ int inc_sync_w0(const Inc &I, int Kf, const Lds &L, c
         Kf = 0;
         wave_sync();
     }
-    {
-        const int r0 = lane, r1 = lane + 64;
-        const bool dead0 = (r0 < Kf) && (L.S[I.ord[r0 < Kf ? r0 : 0]] != SSQP_IN);
-        const bool dead1 = (r1 < Kf) && (L.S[I.ord[r1 < Kf ? r1 : 0]] != SSQP_IN);
-        unsigned long long dm0 = __ballot(dead0), dm1 = __ballot(dead1);
-        while (dm0 | dm1) {
-            int pdel;
-            if (dm1) {
-                pdel = 127 - __clzll(dm1);
-                dm1 &= ~(1ull << (pdel - 64));
-            } else {
-                pdel = 63 - __clzll(dm0);
-                dm0 &= ~(1ull << pdel);
-            }
-            if (Kf <= 64) inc_delete_update<1>(I, Kf, pdel);
-            else inc_delete_update<2>(I, Kf, pdel);
-            inc_delete_compact_w0(I, Kf, pdel);
+    for (int t = 3; t >= 0; --t) {  // row chunks from the top: deleting row p leaves the rows below p in place
+        const int r = lane + 64 * t;
+        const bool dead = (r < Kf) && (L.S[I.ord[r < Kf ? r : 0]] != SSQP_IN);
+        unsigned long long dm = __ballot(dead);
+        while (dm) {
+            const int pdel = 64 * t + 63 - __clzll(dm);
+            dm &= ~(1ull << (pdel - 64 * t));
+            INC_BY_SLOTS(Kf, inc_delete_update<1>(I, Kf, pdel), inc_delete_update<2>(I, Kf, pdel),
+                         inc_delete_update<4>(I, Kf, pdel));
+            INC_BY_SLOTS(Kf, inc_delete_compact<1>(I, Kf, pdel), inc_delete_compact<2>(I, Kf, pdel),
+                         inc_delete_compact<4>(I, Kf, pdel));
             Kf -= 1;
         }
     }
@@ -1239,7 +1275,9 @@ __device__ __forceinline__ int inc_sync_w0(const Inc &I, int Kf, const Lds &L, c
         while (m) {
             const int b = __ffsll((long long)m) - 1;
             m &= m - 1;
-            const bool ok1 = (Kf <= 64) ? inc_append<1>(I, Kf, c0 + b, V, N) : inc_append<2>(I, Kf, c0 + b, V, N);
+            bool ok1 = true;
+            INC_BY_SLOTS(Kf, ok1 = inc_append<1>(I, Kf, c0 + b, V, N), ok1 = inc_append<2>(I, Kf, c0 + b, V, N),
+                         ok1 = inc_append<4>(I, Kf, c0 + b, V, N));
             if (!ok1) return -1;
             Kf += 1;
             nAppended += 1;
@@ -1396,7 +1434,9 @@ struct ProbCtx {
     // incremental engine state
     int Kfac;     // rows currently in the kept factor (0: empty / invalid)
     int RC;       // factor capacity (0: engine disabled for this problem shape)
-    int yOff, rdvOff, facOff;  // arena offsets (doubles)
+    int yOff, rdvOff, facOff;  // offsets (doubles) of Y, 1/d and the factor in their arena
+    int scrCap;                // doubles of scratch in front of them (LDS arena)
+    bool facGlobal;            // engine state (factor, 1/d, Y) lives in the workgroup's GLOBAL arena (K grew past the LDS capacity)
 #ifdef SSQP_PHASE_PROFILE
     unsigned long long ph_last;
     int ph_cur;
@@ -1408,7 +1448,9 @@ enum { ACT_CONTINUE = 0, ACT_BREAK = 1 };
 // One pass of the loop for K > 0, from the E-row sweep to the status switch.
 // INLDS selects where the arena (X, packed factor, Schur block) lives: the
 // instantiation with INLDS=true only ever sees LDS pointers.
-template <int VEC, bool INLDS>
+// FG: the kept factor, its reciprocal pivots and the border right-hand sides live in the global arena (large K);
+// the scratch (X, AXPY staging, Schur block) stays in LDS.
+template <int VEC, bool INLDS, bool FG>
 __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar, int K, int W0, int JO) {
     const int N = C.N, M = C.M, J = C.J, MJ = C.MJ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1430,9 +1472,12 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     bool useInc = false;
     if (INLDS) useInc = (C.RC > 0) && (K <= C.RC) && (W0 + 1 <= INC_RBM);
     Inc I;
-    I.fcol = ar + C.facOff;
-    I.rdv = ar + C.rdvOff;
-    I.Y = ar + C.yOff;
+    {
+        double *eb = FG ? C.garena : ar;  // base of the engine state
+        I.fcol = eb + C.facOff;
+        I.rdv = eb + C.rdvOff;
+        I.Y = eb + C.yOff;
+    }
     I.ord = L.ordl;
     I.fpos = L.fpos;
     I.RC = C.RC;
@@ -1440,7 +1485,8 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     // that fits in registers, and room in the scratch arena for two partial vectors plus X
     bool frontDone = false;
     int Wspec = W0;
-    if (useInc && VEC == 2 && W0 <= RF_ROWS && K + 1 <= 128 && (long)2 * N + (long)W0 * (K + 1) + 8 <= C.yOff) {
+    if (useInc && VEC == 2 && W0 <= RF_ROWS && (W0 <= 4 ? K + 1 <= 256 : K + 1 <= 192) &&
+        (long)2 * N + (long)W0 * (K + 1) + 8 <= C.scrCap) {
         PHASE(C, 1);
         double *X = ar + 2 * N;
         for (int w = wave; w < W0; w += NW) {  // E-row sweep (SSQP.jl:290-295), rows over the wavefronts
@@ -1476,7 +1522,11 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             SUBPHASE(14, tw0);
         } else if (wave == 1) {
             int w = W0;
-            if (W0 > 0) w = (W0 <= 4) ? rank_filter_regs<4, 2>(X, W0, K + 1, tol, L) : rank_filter_wave(X, W0, K + 1, tol, L);
+            if (W0 > 0) {
+                if (W0 <= 4 && K + 1 <= 128) w = rank_filter_regs<4, 2>(X, W0, K + 1, tol, L);
+                else if (W0 <= 4) w = rank_filter_regs<4, 4>(X, W0, K + 1, tol, L);
+                else w = rank_filter_wave(X, W0, K + 1, tol, L);
+            }
             if (w < W0) {
                 const double v = (lane < w) ? L.bE[L.ra[lane < w ? lane : 0]] : 0.0;
                 wave_sync();
@@ -1510,83 +1560,18 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     }
     if (useInc && !frontDone) {
         PHASE(C, 13);
-        int Kf = C.Kfac;
-        if (Kf < 0) {  // the factor was overwritten by a from-scratch pass: start over
-            for (int i = tid; i < N; i += NT) L.fpos[i] = -1;
-            Kf = 0;
-            __syncthreads();
-        }
-        // deletions: rows whose variable is no longer IN (highest row first: cheapest, indices below stay)
-        {
-            const int r = tid;  // rows 0..127 are covered by wavefronts 0 and 1
-            const bool dead = (r < Kf) && (L.S[I.ord[r < Kf ? r : 0]] != SSQP_IN);
-            const unsigned long long m = __ballot(dead);
-            if (lane == 0 && wave < 2) {
-                L.ired[2 * NW + 6 + 2 * wave] = (int)(m & 0xffffffffull);
-                L.ired[2 * NW + 7 + 2 * wave] = (int)(m >> 32);
+        if (wave == 0) {
+            int nApp = 0;
+            const int Kf = inc_sync_w0(I, C.Kfac, L, V, N, nApp);
+            if (lane == 0) {
+                L.ired[2 * NW + 10] = Kf;
+                L.ired[2 * NW + 11] = nApp;
             }
         }
         __syncthreads();
-        unsigned long long dm0 = ((unsigned long long)(unsigned)L.ired[2 * NW + 7] << 32) | (unsigned)L.ired[2 * NW + 6];
-        unsigned long long dm1 = ((unsigned long long)(unsigned)L.ired[2 * NW + 9] << 32) | (unsigned)L.ired[2 * NW + 8];
-        while (dm0 | dm1) {
-            int pdel;
-            if (dm1) {
-                pdel = 127 - __clzll(dm1);
-                dm1 &= ~(1ull << (pdel - 64));
-            } else {
-                pdel = 63 - __clzll(dm0);
-                dm0 &= ~(1ull << pdel);
-            }
-            if (wave == 0) {
-                if (Kf <= 64) inc_delete_update<1>(I, Kf, pdel);
-                else inc_delete_update<2>(I, Kf, pdel);
-            }
-            __syncthreads();
-            inc_delete_compact(I, Kf, pdel);
-            Kf -= 1;
-        }
-        // appends: IN variables that have no row yet, by increasing index
-        int nA = 0;
-        {
-            const int lane_ = lane, wave_ = wave;
-            int base = 0;
-            for (int c0 = 0; c0 < N; c0 += NT) {
-                const int i = c0 + tid;
-                const bool f = (i < N) && (L.S[i] == SSQP_IN) && (L.fpos[i] < 0);
-                const unsigned long long m = __ballot(f);
-                const int lp = __popcll(m & ((1ull << lane_) - 1ull));
-                if (lane_ == 0) L.ired[wave_] = __popcll(m);
-                __syncthreads();
-                int wb = 0, tot = 0;
-#pragma unroll
-                for (int wv = 0; wv < NW; ++wv) {
-                    const int cnt = L.ired[wv];
-                    if (wv < wave_) wb += cnt;
-                    tot += cnt;
-                }
-                if (f) L.perm[base + wb + lp] = (int16_t)i;
-                base += tot;
-                __syncthreads();
-            }
-            nA = base;
-        }
-        bool okA = true;
-        for (int a = 0; a < nA; ++a) {
-            if (wave == 0) {
-                const bool ok1 = (Kf <= 64) ? inc_append<1>(I, Kf, L.perm[a], V, N) : inc_append<2>(I, Kf, L.perm[a], V, N);
-                if (lane == 0) L.ired[2 * NW + 5] = ok1 ? 1 : 0;
-            }
-            __syncthreads();
-            if (!L.ired[2 * NW + 5]) {
-                okA = false;
-                break;
-            }
-            Kf += 1;
-        }
-        C.Kfac = Kf;
-        C.sRead += 64ll * nA * K;  // the K scattered entries of each appended column (one 64-byte sector each)
-        if (!okA) {  // cholesky(V[F,F]) of the reference would throw here
+        C.Kfac = L.ired[2 * NW + 10];
+        C.sRead += 64ll * L.ired[2 * NW + 11] * K;  // the K scattered entries of each appended column
+        if (C.Kfac < 0) {  // cholesky(V[F,F]) of the reference would throw here
             C.ret = -1;
             C.det = SSQP_DETAIL_POSDEF_V;
             return ACT_BREAK;
@@ -1686,8 +1671,8 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         if (tid <= W) L.perm[tid] = (tid < W) ? L.ra[tid] : (int16_t)W0;  // physical right-hand sides
         __syncthreads();
         PHASE(C, 4);
-        if (K <= 64) inc_forward_border<1>(I, K, W + 1, L.perm);
-        else inc_forward_border<2>(I, K, W + 1, L.perm);
+        INC_BY_SLOTS(K, inc_forward_border<1>(I, K, W + 1, L.perm), inc_forward_border<2>(I, K, W + 1, L.perm),
+                     inc_forward_border<4>(I, K, W + 1, L.perm));
         __syncthreads();
         PHASE(C, 5);
         // Schur block: H = AE V^-1 AE' (W x W, lower) into the scratch arena, t = AE V^-1 c into tv.
@@ -1730,26 +1715,12 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             return ACT_BREAK;
         }
         PHASE(C, 6);
-        if (wave == 0) {  // v = D^-1 (Y_A alphaL + y_c); alpha = -L'^-1 v
-            const int r0 = lane, r1 = lane + 64;
-            const double *Yc = I.Y + (size_t)W0 * I.RC;
-            double v0 = (r0 < K) ? Yc[r0] : 0.0, v1 = (r1 < K) ? Yc[r1] : 0.0;
-            for (int w = 0; w < W; ++w) {
-                const double *Yw = I.Y + (size_t)L.perm[w] * I.RC;
-                const double aw = L.aL[w];
-                if (r0 < K) v0 = fma(Yw[r0], aw, v0);
-                if (r1 < K) v1 = fma(Yw[r1], aw, v1);
-            }
-            v0 *= (r0 < K) ? I.rdv[r0] : 0.0;
-            v1 *= (r1 < K) ? I.rdv[r1] : 0.0;
-            if (K <= 64) inc_backward<1>(I, K, v0, v1);
-            else inc_backward<2>(I, K, v0, v1);
-            if (r0 < K) L.gam[I.ord[r0]] = -v0;
-            if (r1 < K) L.gam[I.ord[r1]] = -v1;
-        }
+        if (wave == 0)  // v = D^-1 (Y_A alphaL + y_c); alpha = -L'^-1 v
+            INC_BY_SLOTS(K, inc_alpha<1>(I, K, W, W0, L.perm, L.aL, L.gam), inc_alpha<2>(I, K, W, W0, L.perm, L.aL, L.gam),
+                         inc_alpha<4>(I, K, W, W0, L.perm, L.aL, L.gam));
         __syncthreads();
     } else {
-        if (INLDS) C.Kfac = -1;  // the from-scratch path overwrites the arena: the kept factor is gone
+        C.Kfac = -1;  // the from-scratch path overwrites the arena: the kept factor is gone
     // ---- factor assembly: pass 1 over V[:,F] + border rows ----
     PHASE(C, 3);
     const int Rr = K + W + 1;
@@ -2129,6 +2100,8 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
     C.Kfac = 0;
     C.RC = 0;
     C.yOff = C.rdvOff = C.facOff = 0;
+    C.scrCap = P.arenaCap;
+    C.facGlobal = false;
     if (P.incremental) {
         int rc = INC_KMAX;
         for (; rc >= 16; rc -= 2) {
@@ -2138,6 +2111,7 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
             const long need = scr + (long)INC_RBM * rc + rc + (long)rc * (rc + 1) / 2 + 8;
             if (need <= P.arenaCap) {
                 C.RC = rc;
+                C.scrCap = (int)scr;
                 C.yOff = (int)scr;
                 C.rdvOff = C.yOff + INC_RBM * rc;
                 C.facOff = C.rdvOff + rc;
@@ -2228,9 +2202,36 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
         if (needLS > needF) needF = needLS;
         const bool inLds = (needX <= P.arenaCap) && (needF <= P.arenaCap);
         C.pathBits |= inLds ? 1 : 2;
+        // kept-factor engine in the global arena: when K outgrows the LDS factor capacity (up to 256 rows)
+        const int RCg = (N < INC_KMAX) ? N : INC_KMAX;
+        const bool scratchFits = (long)W0 * (K + 2) + 64 <= P.arenaCap && (long)NW * N + 64 <= P.arenaCap;
+        if (P.incremental && !C.facGlobal && K > C.RC && K <= RCg && W0 + 1 <= INC_RBM && scratchFits) {
+            // migrate: copy the factor to the global layout (capacity RCg) and continue there
+            const int Kf = (C.Kfac > 0 && C.RC > 0) ? C.Kfac : 0;
+            double *g0 = garena + ((long)NW * N + 64);          // the front of the global arena stays AXPY staging
+            const int yOffG = 0, rdvOffG = INC_RBM * RCg, facOffG = rdvOffG + RCg;
+            for (int c = wave; c < Kf; c += NW) {
+                const int os = cofs(c, C.RC) - c, od = cofs(c, RCg) - c;
+                for (int r = c + lane; r < Kf; r += 64) g0[facOffG + od + r] = L.arena[C.facOff + os + r];
+            }
+            for (int r = tid; r < Kf; r += NT) g0[rdvOffG + r] = L.arena[C.rdvOff + r];
+            if (C.Kfac < 0 || C.RC == 0) {
+                for (int i = tid; i < N; i += NT) L.fpos[i] = -1;
+                C.Kfac = 0;
+            }
+            C.facGlobal = true;
+            C.RC = RCg;
+            C.yOff = (int)((long)NW * N + 64) + yOffG;
+            C.rdvOff = (int)((long)NW * N + 64) + rdvOffG;
+            C.facOff = (int)((long)NW * N + 64) + facOffG;
+            C.scrCap = P.arenaCap;
+            C.pathBits |= 8;
+            __syncthreads();
+        }
         int act;
-        if (inLds) act = iterate_kkt<VEC, true>(C, L, L.arena, K, W0, JO);
-        else act = iterate_kkt<VEC, false>(C, L, garena, K, W0, JO);
+        if (C.facGlobal && K <= C.RC && W0 + 1 <= INC_RBM && scratchFits) act = iterate_kkt<VEC, true, true>(C, L, L.arena, K, W0, JO);
+        else if (inLds) act = iterate_kkt<VEC, true, false>(C, L, L.arena, K, W0, JO);
+        else act = iterate_kkt<VEC, false, false>(C, L, garena, K, W0, JO);
         if (act == ACT_BREAK) break;
     }
     __syncthreads();

@@ -2,6 +2,9 @@
 
 Bar (BASELINE.json north_star): status vectors bit-exact, iteration counts equal,
 z within 1e-10 relative (Float64)."""
+import glob
+import os
+
 import numpy as np
 import pytest
 
@@ -59,8 +62,16 @@ def test_cfg2_n512(pkg, orc):
 
 
 def test_cfg3_n256_large_k_global_arena(pkg, orc):
-    rel, stats = run_cfg(pkg, orc, pkg.CONFIGS["cfg3"], 2)
+    """K grows to ~220: the kept factor outgrows LDS and migrates to the workgroup's global arena (path bit 8)"""
+    rel, stats = run_cfg(pkg, orc, pkg.CONFIGS["cfg3"], 8)
     assert stats["max_k"].max() > 180
+    assert ((stats["path"] & 8) != 0).all()
+    os.environ["SSQP_INCREMENTAL"] = "0"          # from-scratch factorisation out of the global arena
+    try:
+        rel, stats = run_cfg(pkg, orc, pkg.CONFIGS["cfg3"], 2)
+    finally:
+        os.environ["SSQP_INCREMENTAL"] = "1"
+    assert ((stats["path"] & 2) != 0).all()
 
 
 def test_trace_matches_oracle(pkg, orc):
