@@ -204,3 +204,53 @@ def test_incremental_and_from_scratch_agree(pkg, orc):
         finally:
             os.environ["SSQP_INCREMENTAL"] = "1"
         assert (((stats["path"] & 4) != 0).all()) == (inc == "1")
+
+
+def _mutate(prob, rng, kind):
+    """variations the plain generator does not produce"""
+    P, N = prob["q"].shape
+    if kind == "lower_bounds":          # nonzero lower bounds: bound variables at DN carry weight in V[:,B] zB
+        prob["d"][:] = rng.uniform(0.0, 0.3 / N, size=(P, N))
+        prob["u"][:] = prob["d"] + rng.uniform(0.5 / N, 4.0 / N, size=(P, N)) + 1.0 / N
+    elif kind == "negative_lower":      # shorting allowed
+        prob["d"][:] = -rng.uniform(0.0, 1.0 / N, size=(P, N))
+    elif kind == "dup_rows" and prob["G"].shape[2] >= 2:   # dependent inequality rows -> rank filter purges
+        J = prob["G"].shape[2]
+        G = prob["G"].reshape(P, N, J)
+        G[:, :, 1] = G[:, :, 0]
+        prob["g"][:, 1] = prob["g"][:, 0]
+    elif kind == "some_free":           # a few variables without bounds
+        prob["d"][:, :3] = -np.inf
+        prob["u"][:, :3] = np.inf
+    elif kind == "big_q":
+        prob["q"][:] *= 5.0
+    return prob
+
+
+@pytest.mark.parametrize("kind", ["plain", "lower_bounds", "negative_lower", "dup_rows", "some_free", "big_q"])
+def test_random_shapes_and_bounds(pkg, orc, kind):
+    """many small random problems of mixed shapes; every one must match the oracle decision for decision"""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(kind.encode()))
+    shapes = [(24, 1, 0), (40, 1, 3), (57, 2, 4), (64, 1, 6), (96, 3, 8), (130, 1, 10), (150, 2, 5), (200, 1, 2)]
+    total = 0
+    for (N, M, J) in shapes:
+        ub = rng.uniform(2.0, 6.0) / N if kind != "some_free" else 0.0
+        cfg = pkg.GenConfig(N, M, J, 2 * N, 1e-3, ub, rng.uniform(0.93, 1.1), rng.uniform(0.0, 0.3))
+        prob = pkg.generate_batch(cfg, 12, int(rng.integers(1, 2 ** 31)))
+        prob = _mutate(prob, rng, kind)
+        x0, S0, st = pkg.phase1_batch(prob)
+        ok = st == 1
+        if not ok.any():
+            continue
+        sub = {k: np.ascontiguousarray(v[ok]) for k, v in prob.items()}
+        z, S, status, detail = pkg.solveQP_batch(sub, S0[ok], x0[ok])
+        zo, So, sto, deto, _ = oracle_batch(orc, sub, S0[ok], x0[ok])
+        conv = sto > 0
+        assert np.array_equal(status, sto), (kind, N, M, J, status, sto)
+        assert np.array_equal(S[conv], So[conv])
+        fin = np.isfinite(zo).all(axis=1) & conv
+        scale = np.maximum(np.abs(zo[fin]).max(axis=1), 1e-300)
+        assert (np.abs(z[fin] - zo[fin]).max(axis=1) / scale).max() < 1e-10 if fin.any() else True
+        total += int(conv.sum())
+    assert total > 40
