@@ -1550,11 +1550,15 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         }
         Wspec = L.ired[2 * NW + 4];
         C.sRead += 64ll * L.ired[2 * NW + 11] * K + 8ll * N * L.ired[2 * NW + 12] - 8ll * N * K;
-        for (int i = tid; i < N; i += NT) L.gam[i] = ar[i] + ar[N + i];  // hB = sum of the two partial vectors
         for (int e = tid; e < W0 * K; e += NT) {  // border right-hand sides AE' in factor order (X may be consumed
             const int w = e / K, r = e - w * K;     //  by the rank filter: re-gather from the constraint rows)
             I.Y[(size_t)w * I.RC + r] = Ct[(size_t)L.rowsE[w] * N + I.ord[r]];
         }
+        for (int r = tid; r < K; r += NT) {  // c = hB[F] + q[F]; hB = sum of the two partial vectors, only F is needed
+            const int i = I.ord[r];
+            I.Y[(size_t)W0 * I.RC + r] = (ar[i] + ar[N + i]) + q[i];
+        }
+        if (tid <= Wspec) L.perm[tid] = (tid < Wspec) ? L.ra[tid] : (int16_t)W0;  // physical right-hand sides
         __syncthreads();
         frontDone = true;
     }
@@ -1664,12 +1668,14 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             C.sRead += 8ll * N * ncols - 8ll * N * K;  // (the K term is added by the common accounting below)
             __syncthreads();
         }
-        for (int r = tid; r < K; r += NT) {
-            const int i = I.ord[r];
-            I.Y[(size_t)W0 * I.RC + r] = L.gam[i] + q[i];
+        if (!frontDone) {
+            for (int r = tid; r < K; r += NT) {
+                const int i = I.ord[r];
+                I.Y[(size_t)W0 * I.RC + r] = L.gam[i] + q[i];
+            }
+            if (tid <= W) L.perm[tid] = (tid < W) ? L.ra[tid] : (int16_t)W0;  // physical right-hand sides
+            __syncthreads();
         }
-        if (tid <= W) L.perm[tid] = (tid < W) ? L.ra[tid] : (int16_t)W0;  // physical right-hand sides
-        __syncthreads();
         PHASE(C, 4);
         INC_BY_SLOTS(K, inc_forward_border<1>(I, K, W + 1, L.perm), inc_forward_border<2>(I, K, W + 1, L.perm),
                      inc_forward_border<4>(I, K, W + 1, L.perm));
