@@ -872,43 +872,48 @@ __device__ __forceinline__ bool bordered_ldl(double *fac, double *rd, int jb, in
             __syncthreads();
             return false;
         }
-        // ---- rank-nb update of the trailing columns (border and Schur block included)
-        int op[4];
-        double rp[4];
+        // ---- rank-nb update of the trailing columns (border and Schur block included) on the matrix cores:
+        // the trailing triangle is cut into 16x16 tiles and each tile gets ONE v_mfma_f64_16x16x4_f64,
+        //   D(16x16) = C - A(16x4) * B(4x16),  A = L(rows, panel),  B = (L(cols, panel) * 1/d)'
+        // f64 MFMA fragment layout (cdna_hip_programming.md section 3): lane l holds A[l&15][l>>4] and B[l>>4][l&15];
+        // C/D register g of lane l is element (row (l>>4) + 4g, col l&15).
+        {
+            using f64x4 = __attribute__((ext_vector_type(4))) double;
+            const int jt = j + nb;                       // first trailing column
+            const int nt = (R - jt + 15) >> 4;           // tiles per dimension
+            const int kk = lane >> 4, l15 = lane & 15;
+            const int jc = j + (kk < nb ? kk : nb - 1);  // this lane's panel column
+            const int opc = coloff(jc, R) - jc;
+            const double rpk = (kk < nb) ? rd[jc] : 0.0;
+            for (int t = wave; t < nt * (nt + 1) / 2; t += NW) {
+                int tk = 0, f = t;  // lower-triangular tile index -> (ti >= tk), column-major over tile columns
+                while (f >= nt - tk) {
+                    f -= nt - tk;
+                    ++tk;
+                }
+                const int ti = tk + f;
+                const int i0 = jt + 16 * ti, k0 = jt + 16 * tk;
+                const int ra_ = i0 + l15, cb_ = k0 + l15;
+                const double av = fac[opc + (ra_ < R ? ra_ : jc)];
+                const double bv = fac[opc + (cb_ < R ? cb_ : jc)];
+                const double a = (ra_ < R && kk < nb) ? -av : 0.0;
+                const double bb = (cb_ < R && kk < nb) ? bv * rpk : 0.0;
+                const int colc = (cb_ < R) ? cb_ : jt;
+                const int occ = coloff(colc, R) - colc;
+                f64x4 cv;
+                bool ok[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int jc = j + (c < nb ? c : nb - 1);
-            op[c] = coloff(jc, R) - jc;
-            rp[c] = (c < nb) ? rd[jc] : 0.0;
-        }
-        for (int k0 = j + nb + wave * 4; k0 < R; k0 += NW * 4) {
-            double f[4][4];
-            int ok_[4], kq[4];
+                for (int g = 0; g < 4; ++g) {
+                    const int row = i0 + kk + 4 * g;
+                    ok[g] = (cb_ < R) && (row < R) && (row >= cb_);
+                    cv[g] = fac[occ + (ok[g] ? row : colc)];
+                    cv[g] = ok[g] ? cv[g] : 0.0;
+                }
+                cv = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, cv, 0, 0, 0);
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                kq[q4] = (k0 + q4 < R) ? k0 + q4 : k0;
-                ok_[q4] = coloff(kq[q4], R) - kq[q4];
-            }
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) f[q4][c] = fac[op[c] + kq[q4]];  // 16 independent LDS reads
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) f[q4][c] = (k0 + q4 < R) ? f[q4][c] * rp[c] : 0.0;
-            for (int i = k0 + lane; i < R; i += 64) {
-                double ai[4], v[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) ai[c] = fac[op[c] + i];
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) v[q4] = fac[ok_[q4] + (i >= kq[q4] ? i : kq[q4])];
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    double t = v[q4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) t = fma(-f[q4][c], ai[c], t);
-                    if (i >= k0 + q4 && k0 + q4 < R) fac[ok_[q4] + i] = t;
+                for (int g = 0; g < 4; ++g) {
+                    const int row = i0 + kk + 4 * g;
+                    if (ok[g]) fac[occ + row] = cv[g];
                 }
             }
         }
