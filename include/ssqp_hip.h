@@ -137,6 +137,19 @@ int ssqp_solve_batch_dev_f64(ssqp_ctx *ctx, int nprob, int N, int M, int J, cons
                              const double *du, int32_t *dS, const double *dx0, double *dz,
                              const ssqp_settings *settings, int64_t *dstatus, int32_t *ddetail,
                              ssqp_stats *dstats, ssqp_trace *dtrace, int ntrace, void *stream);
+/* The same with per-array problem strides in ELEMENTS (NULL = dense batch as above; a stride of 0 = that array is
+ * shared by every problem).  Efficient-frontier style batches -- QP(P, q, L) / QP(P, mu, q) of the reference
+ * (src/types.jl:303-339): one V (and A, G, d, u) for many q or b -- then read V out of L2 / Infinity Cache. */
+typedef struct ssqp_batch_strides {
+    size_t V, A, G, q, b, g, d, u;
+} ssqp_batch_strides;
+int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *ctx, int nprob, int N, int M, int J, const double *dV,
+                                     const double *dA, const double *dG, const double *dq,
+                                     const double *db, const double *dg, const double *dd,
+                                     const double *du, const ssqp_batch_strides *strides, int32_t *dS,
+                                     const double *dx0, double *dz, const ssqp_settings *settings,
+                                     int64_t *dstatus, int32_t *ddetail, ssqp_stats *dstats,
+                                     ssqp_trace *dtrace, int ntrace, void *stream);
 int ssqp_sync(ssqp_ctx *ctx, void *stream);
 /* duration in ms of the solve kernel of the most recent ssqp_solve_batch_dev_f64
  * on this ctx, from HIP events recorded on the launch stream (call after sync) */

@@ -36,6 +36,10 @@ class CTrace(C.Structure):
     _fields_ = [("K", C.c_int32), ("W", C.c_int32), ("kind", C.c_int32), ("id", C.c_int32)]
 
 
+class CStrides(C.Structure):
+    _fields_ = [(k, C.c_size_t) for k in ("V", "A", "G", "q", "b", "g", "d", "u")]
+
+
 class CGenCfg(C.Structure):
     _fields_ = [("N", C.c_int32), ("M", C.c_int32), ("J", C.c_int32), ("T", C.c_int32), ("delta", C.c_double),
                 ("ub", C.c_double), ("gscale", C.c_double), ("qscale", C.c_double)]
@@ -60,6 +64,8 @@ SIGNATURES = {
                                                                           _vp, _vp, _vp]),
     "ssqp_solve_batch_dev_f64": (C.c_int, [_vp] + [C.c_int] * 4 + [_vp] * 8 + [_vp, _vp, _vp, C.POINTER(CSettings),
                                                                               _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "ssqp_solve_batch_strided_dev_f64": (C.c_int, [_vp] + [C.c_int] * 4 + [_vp] * 8 + [C.POINTER(CStrides)] +
+                                         [_vp, _vp, _vp, C.POINTER(CSettings), _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "ssqp_sync": (C.c_int, [_vp, _vp]),
     "ssqp_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "ssqp_phase1_f64": (C.c_int, [C.c_int] * 3 + [_vp] * 6 + [C.POINTER(CSettings), _vp, _vp, _ip]),

@@ -133,11 +133,15 @@ int ssqp_last_kernel_ms(ssqp_ctx *c, float *ms) {
     return hip_ok(c, hipEventElapsedTime(ms, c->ev0, c->ev1), "hipEventElapsedTime") ? SSQP_OK : SSQP_ERR_HIP;
 }
 
-int ssqp_solve_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const double *dV, const double *dA,
-                             const double *dG, const double *dq, const double *db, const double *dg,
-                             const double *dd, const double *du, int32_t *dS, const double *dx0, double *dz,
-                             const ssqp_settings *settings, int64_t *dstatus, int32_t *ddetail,
-                             ssqp_stats *dstats, ssqp_trace *dtrace, int ntrace, void *stream) {
+int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const double *dV, const double *dA,
+                                     const double *dG, const double *dq, const double *db, const double *dg,
+                                     const double *dd, const double *du, const ssqp_batch_strides *strides,
+                                     int32_t *dS, const double *dx0, double *dz, const ssqp_settings *settings,
+                                     int64_t *dstatus, int32_t *ddetail, ssqp_stats *dstats, ssqp_trace *dtrace,
+                                     int ntrace, void *stream) {
+    ssqp_batch_strides st0;
+    st0.V = (size_t)N * N; st0.A = (size_t)M * N; st0.G = (size_t)J * N; st0.q = N; st0.b = M; st0.g = J; st0.d = N; st0.u = N;
+    const ssqp_batch_strides *sd = strides ? strides : &st0;
     int rc = check_dims(c, nprob, N, M, J);
     if (rc != SSQP_OK) return rc;
     if (!dV || !dq || !dd || !du || !dS || !dx0 || !dz || !dstatus || (M > 0 && (!dA || !db)) ||
@@ -185,6 +189,11 @@ int ssqp_solve_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const 
     P.Ct = (const double *)c->Ct.p;
     P.rhs = (const double *)c->rhs.p;
     P.q = dq; P.d = dd; P.u = du; P.x0 = dx0;
+    const bool sharedC = (sd->A == 0 || M == 0) && (sd->G == 0 || J == 0) && MJ > 0;
+    const bool sharedR = (sd->b == 0 || M == 0) && (sd->g == 0 || J == 0) && MJ > 0;
+    P.sV = sd->V; P.sq = sd->q; P.sd = sd->d; P.su = sd->u;
+    P.sCt = sharedC ? 0 : (size_t)MJ * N;
+    P.sRhs = sharedR ? 0 : (size_t)MJ;
     P.S = dS; P.z = dz; P.status = dstatus; P.detail = ddetail; P.stats = dstats;
     P.trace = (ntrace > 0) ? dtrace : nullptr;
     P.ntrace = (dtrace && ntrace > 0) ? ntrace : 0;
@@ -208,13 +217,23 @@ int ssqp_solve_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const 
     }
 
     if (!hip_ok(c, hipMemsetAsync(c->queue.p, 0, 64, s), "hipMemsetAsync")) return SSQP_ERR_HIP;
-    ssqp::launch_prep(nprob, N, M, J, dA, dG, db, dg, (double *)c->Ct.p, (double *)c->rhs.p, s);
+    ssqp::launch_prep(sharedC ? 1 : nprob, sharedR ? 1 : nprob, N, M, J, dA, dG, db, dg, sd->A, sd->G, sd->b, sd->g,
+                      (double *)c->Ct.p, (double *)c->rhs.p, s);
     if (!hip_ok(c, hipGetLastError(), "prep launch")) return SSQP_ERR_HIP;
     if (!hip_ok(c, hipEventRecord(c->ev0, s), "hipEventRecord")) return SSQP_ERR_HIP;
     if (!hip_ok(c, ssqp::launch_solve(P, grid, (size_t)lay.total_bytes, wgPerCU, s), "solve launch")) return SSQP_ERR_HIP;
     if (!hip_ok(c, hipEventRecord(c->ev1, s), "hipEventRecord")) return SSQP_ERR_HIP;
     c->timed = true;
     return SSQP_OK;
+}
+
+int ssqp_solve_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const double *dV, const double *dA,
+                             const double *dG, const double *dq, const double *db, const double *dg,
+                             const double *dd, const double *du, int32_t *dS, const double *dx0, double *dz,
+                             const ssqp_settings *settings, int64_t *dstatus, int32_t *ddetail,
+                             ssqp_stats *dstats, ssqp_trace *dtrace, int ntrace, void *stream) {
+    return ssqp_solve_batch_strided_dev_f64(c, nprob, N, M, J, dV, dA, dG, dq, db, dg, dd, du, nullptr, dS, dx0, dz,
+                                            settings, dstatus, ddetail, dstats, dtrace, ntrace, stream);
 }
 
 int ssqp_generate_V_dev(ssqp_ctx *c, const ssqp_gen_cfg *cfg, uint64_t seed0, int nprob, double *dV, void *stream) {

@@ -26,6 +26,7 @@ struct SolveParams {
     const double *Ct;   // nprob x (MJ x N): row r of [A;G] contiguous
     const double *rhs;  // nprob x MJ: [b; g]
     const double *q, *d, *u, *x0;
+    size_t sV, sCt, sRhs, sq, sd, su;  // per-problem element strides (0 = shared by the batch)
     int32_t *S;
     double *z;
     int64_t *status;
@@ -110,8 +111,9 @@ inline size_t global_arena_doubles(int N, int M, int J) {
     return (x > f ? x : f) + 64;
 }
 
-void launch_prep(int nprob, int N, int M, int J, const double *A, const double *G, const double *b,
-                 const double *g, double *Ct, double *rhs, hipStream_t stream);
+void launch_prep(int nct, int nrhs, int N, int M, int J, const double *A, const double *G, const double *b,
+                 const double *g, size_t sA, size_t sG, size_t sb, size_t sg, double *Ct, double *rhs,
+                 hipStream_t stream);
 hipError_t launch_genV(int nprob, int N, int T, double delta, unsigned long long seed0, double *V, hipStream_t stream);
 hipError_t launch_solve(const SolveParams &P, int grid, size_t ldsBytes, int wgPerCU, hipStream_t stream);
 

@@ -2084,12 +2084,13 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
     ProbCtx C;
     C.N = N; C.M = M; C.J = J; C.MJ = P.MJ;
     C.tol = P.tol; C.tolG = P.tolG;
-    C.V = P.V + (size_t)prob * N * N;
-    C.Ct = P.Ct + (size_t)prob * N * P.MJ;
-    C.rhs = P.rhs + (size_t)prob * P.MJ;
-    C.q = P.q + (size_t)prob * N;
-    C.dlo = P.d + (size_t)prob * N;
-    C.uhi = P.u + (size_t)prob * N;
+    // per-problem strides (elements); 0 = one array shared by the whole batch (efficient-frontier style batches)
+    C.V = P.V + (size_t)prob * P.sV;
+    C.Ct = P.Ct + (size_t)prob * P.sCt;
+    C.rhs = P.rhs + (size_t)prob * P.sRhs;
+    C.q = P.q + (size_t)prob * P.sq;
+    C.dlo = P.d + (size_t)prob * P.sd;
+    C.uhi = P.u + (size_t)prob * P.su;
     C.trace = P.trace ? P.trace + (size_t)prob * P.ntrace : nullptr;
     C.ntrace = P.ntrace;
     C.arenaCap = P.arenaCap;
@@ -2325,47 +2326,40 @@ __global__ __launch_bounds__(NT, WPS) void ssqp_solve_kernel(SolveParams P) {
     }
 }
 
-// Ct[p][r][i] = [A;G][r, i]: constraint rows made contiguous; rhs = [b; g]
-__global__ void ssqp_prep_kernel(int nprob, int N, int M, int J, const double *__restrict__ A,
+// Ct[p][r][i] = [A;G][r, i]: constraint rows made contiguous; rhs = [b; g].  nct / nrhs = number of distinct
+// Ct / rhs images (1 when A and G, resp. b and g, are shared by the batch); sA.. = element strides (0 = shared).
+__global__ void ssqp_prep_kernel(int nct, int nrhs, int N, int M, int J, const double *__restrict__ A,
                                  const double *__restrict__ G, const double *__restrict__ b,
-                                 const double *__restrict__ g, double *__restrict__ Ct,
-                                 double *__restrict__ rhs) {
+                                 const double *__restrict__ g, size_t sA, size_t sG, size_t sb, size_t sg,
+                                 double *__restrict__ Ct, double *__restrict__ rhs) {
     const int MJ = M + J;
-    const size_t total = (size_t)nprob * MJ * N;
+    const size_t total = (size_t)nct * MJ * N;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (size_t)gridDim.x * blockDim.x) {
         const size_t p = e / ((size_t)MJ * N);
         const size_t rem = e - p * (size_t)MJ * N;
         const int r = (int)(rem / N), i = (int)(rem - (size_t)r * N);
-        Ct[e] = (r < M) ? A[p * (size_t)M * N + (size_t)i * M + r]
-                        : G[p * (size_t)J * N + (size_t)i * J + (r - M)];
+        Ct[e] = (r < M) ? A[p * sA + (size_t)i * M + r] : G[p * sG + (size_t)i * J + (r - M)];
     }
-    const size_t tr = (size_t)nprob * MJ;
+    const size_t tr = (size_t)nrhs * MJ;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tr; e += (size_t)gridDim.x * blockDim.x) {
         const size_t p = e / MJ;
         const int r = (int)(e - p * MJ);
-        rhs[e] = (r < M) ? b[p * M + r] : g[p * J + (r - M)];
+        rhs[e] = (r < M) ? b[p * sb + r] : g[p * sg + (r - M)];
     }
 }
 
-void launch_prep(int nprob, int N, int M, int J, const double *A, const double *G, const double *b,
-                 const double *g, double *Ct, double *rhs, hipStream_t stream) {
-    if (M + J == 0 || nprob == 0) return;
-    const size_t total = (size_t)nprob * (M + J) * N;
+void launch_prep(int nct, int nrhs, int N, int M, int J, const double *A, const double *G, const double *b,
+                 const double *g, size_t sA, size_t sG, size_t sb, size_t sg, double *Ct, double *rhs,
+                 hipStream_t stream) {
+    if (M + J == 0 || (nct == 0 && nrhs == 0)) return;
+    const size_t total = (size_t)(nct > nrhs ? nct : nrhs) * (M + J) * N;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(ssqp_prep_kernel, dim3(blocks), dim3(256), 0, stream, nprob, N, M, J, A, G, b, g, Ct, rhs);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(ssqp_prep_kernel, dim3(blocks), dim3(256), 0, stream, nct, nrhs, N, M, J, A, G, b, g, sA, sG, sb,
+                       sg, Ct, rhs);
 }
-
-template <int VEC, int WPS>
-static hipError_t launch_one(const SolveParams &P, int grid, size_t ldsBytes, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ssqp_solve_kernel<VEC, WPS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ssqp_solve_kernel<VEC, WPS>), dim3(grid), dim3(NT), ldsBytes, stream, P);
-    return hipGetLastError();
-}
-
 
 // ---------------------------------------------------------------- synthetic V on the device
 // Bit-identical to generate_one() in ssqp_host.cpp: X[t,i] = u01(stream X, t + T*i) - 1/2,
@@ -2433,6 +2427,16 @@ hipError_t launch_genV(int nprob, int N, int T, double delta, unsigned long long
     hipLaunchKernelGGL(ssqp_genV_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, nprob, N, T, delta, seed0, V);
     return hipGetLastError();
 }
+
+template <int VEC, int WPS>
+static hipError_t launch_one(const SolveParams &P, int grid, size_t ldsBytes, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ssqp_solve_kernel<VEC, WPS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ssqp_solve_kernel<VEC, WPS>), dim3(grid), dim3(NT), ldsBytes, stream, P);
+    return hipGetLastError();
+}
+
 
 hipError_t launch_solve(const SolveParams &P, int grid, size_t ldsBytes, int wgPerCU, hipStream_t stream) {
     // load/accumulate mode: see stream_matvec

@@ -222,7 +222,7 @@ class DeviceBatch:
         self.torch = torch
         self.ctx = ctx or default_context()
         dev = torch.device("cuda", self.ctx.device if device is None else device)
-        self.P, self.N = prob["q"].shape
+        self.P, self.N = np.shape(x0)
         self.M, self.J = prob["b"].shape[1], prob["g"].shape[1]
         self.t = {k: torch.from_numpy(_f64(prob[k])).to(dev) for k in "AGqbgdu"}
         if _gen is None:
@@ -251,15 +251,19 @@ class DeviceBatch:
         return C.c_void_p(t.data_ptr()) if t.numel() else None
 
     def solve(self, settings=None, stream=None):
-        """One pass of the hot path over the batch (asynchronous on `stream`, default torch's current stream)."""
+        """One pass of the hot path over the batch (asynchronous on `stream`, default torch's current stream).
+        Arrays given with a leading dimension of 1 are shared by every problem of the batch (stride 0)."""
         torch = self.torch
         cs = _csettings(settings)
         self.S.copy_(self.S0)  # S is in/out
         if stream is None:
             stream = torch.cuda.current_stream(self.S.device).cuda_stream
         t = self.t
-        rc = _capi.lib().ssqp_solve_batch_dev_f64(
-            self.ctx.handle, self.P, self.N, self.M, self.J, *[self._ptr(t[k]) for k in "VAGqbgdu"],
+        per = dict(V=self.N * self.N, A=self.M * self.N, G=self.J * self.N, q=self.N, b=self.M, g=self.J, d=self.N,
+                   u=self.N)
+        strides = _capi.CStrides(*[(0 if (t[k].shape[0] == 1 and self.P > 1) else per[k]) for k in "VAGqbgdu"])
+        rc = _capi.lib().ssqp_solve_batch_strided_dev_f64(
+            self.ctx.handle, self.P, self.N, self.M, self.J, *[self._ptr(t[k]) for k in "VAGqbgdu"], C.byref(strides),
             self._ptr(self.S), self._ptr(self.x0), self._ptr(self.z), C.byref(cs), self._ptr(self.status),
             self._ptr(self.detail), self._ptr(self.stats), self._ptr(self.trace) if self.ntrace else None,
             self.ntrace, C.c_void_p(stream))

@@ -254,3 +254,25 @@ def test_random_shapes_and_bounds(pkg, orc, kind):
         assert (np.abs(z[fin] - zo[fin]).max(axis=1) / scale).max() < 1e-10 if fin.any() else True
         total += int(conv.sum())
     assert total > 40
+
+
+def test_shared_v_batch_efficient_frontier_style(pkg, orc):
+    """One V, A, G, d, u for the whole batch, only q differs per problem -- QP(P, q, L) of the reference
+    (src/types.jl:303-319) swept over L: the strided entry point with stride 0 on the shared arrays."""
+    cfg = pkg.GenConfig(128, 1, 4, 256, 1e-3, 0.05, 1.05, 1.0)
+    base = pkg.generate_batch(cfg, 1, 31337)
+    Ls = np.linspace(0.0, 2.0, 24)
+    P = len(Ls)
+    q = np.ascontiguousarray(Ls[:, None] * base["q"][0][None, :])          # q_L = -L * mu
+    full = {k: np.ascontiguousarray(np.repeat(base[k], P, axis=0)) for k in "VAGbgdu"}
+    full["q"] = q
+    x0, S0, st = pkg.phase1_batch(full)
+    assert (st == 1).all()
+    shared = dict(base)
+    shared["q"] = q
+    db = pkg.DeviceBatch(shared, S0, x0)           # V, A, G, b, g, d, u have leading dimension 1 -> stride 0
+    db.solve()
+    r = db.results()
+    zo, So, sto, _, _ = oracle_batch(orc, full, S0, x0)
+    assert_parity(r["z"], r["S"], r["status"], zo, So, sto)
+    assert len(set(map(tuple, r["S"]))) > 3       # the frontier really moves through different active sets
