@@ -60,7 +60,7 @@ __host__ __device__ inline int lds_fixed_bytes(int N, int M, int J) {
     int dbl = 3 * align_up(N, 2) + 5 * MJ1 + 2 * NW;
     int bytes = dbl * 8;
     bytes += align_up(4 * (N + J), 8);           // S
-    bytes += align_up(4 * (2 * NW + 16), 8);     // ired
+    bytes += align_up(4 * (2 * NW + 16 + NW * MAXPT), 8);  // ired (+ per-chunk wave counts of the compaction)
     bytes += 4 * align_up(2 * (N + 2), 8);       // pos, idx, fpos, ordl
     bytes += align_up(2 * (N + M + J + 4), 8);   // perm (column list of the AXPY pass: N columns + constraint rows + q)
     bytes += 3 * align_up(2 * (M + J + 2), 8);   // rowsE, ra, iO
@@ -83,7 +83,7 @@ __host__ __device__ inline LdsLayout lds_layout(int N, int M, int J, int arenaCa
     l.arena = o; o += align_up(arenaCap, 2);
     int b = o * 8;
     l.S_bytes = b; b += align_up(4 * (N + J), 8);
-    l.ired_bytes = b; b += align_up(4 * (2 * NW + 16), 8);
+    l.ired_bytes = b; b += align_up(4 * (2 * NW + 16 + NW * MAXPT), 8);
     l.pos_bytes = b; b += align_up(2 * (N + 2), 8);
     l.idx_bytes = b; b += align_up(2 * (N + 2), 8);
     l.perm_bytes = b; b += align_up(2 * (N + M + J + 4), 8);

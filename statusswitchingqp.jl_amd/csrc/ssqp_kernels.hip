@@ -56,12 +56,12 @@ __device__ __forceinline__ double sub_mul_nc(double x, double d, double y) {
 
 // ---- diagnostic build only (-DSSQP_PHASE_PROFILE): cycles per phase, thread 0 of each workgroup ----
 #ifdef SSQP_PHASE_PROFILE
-__device__ unsigned long long g_phase[1024 * 16];
+__device__ unsigned long long g_phase[1024 * 32];
 #define PHASE(C, n)                                                        \
     do {                                                                   \
         if (threadIdx.x == 0) {                                            \
             const unsigned long long t_ = __builtin_amdgcn_s_memtime();    \
-            g_phase[(blockIdx.x & 1023) * 16 + (C).ph_cur] += t_ - (C).ph_last; \
+            (void)__hip_atomic_fetch_add(&g_phase[(blockIdx.x & 1023) * 32 + (C).ph_cur], t_ - (C).ph_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
             (C).ph_last = t_;                                              \
             (C).ph_cur = (n);                                              \
         }                                                                  \
@@ -70,14 +70,19 @@ __device__ unsigned long long g_phase[1024 * 16];
     do {                                                                       \
         if (threadIdx.x == 0) {                                                \
             const unsigned long long t_ = __builtin_amdgcn_s_memtime();        \
-            g_phase[(blockIdx.x & 1023) * 16 + (slot)] += t_ - (t0);           \
+            (void)__hip_atomic_fetch_add(&g_phase[(blockIdx.x & 1023) * 32 + (slot)], t_ - (t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
             (t0) = t_;                                                         \
         }                                                                      \
+    } while (0)
+#define PCOUNT(slot)                                                           \
+    do {                                                                       \
+        if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&g_phase[(blockIdx.x & 1023) * 32 + (slot)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
     } while (0)
 #define SUBPHASE_DECL(t0) unsigned long long t0 = __builtin_amdgcn_s_memtime()
 #else
 #define PHASE(C, n) do { } while (0)
 #define SUBPHASE(slot, t0) do { } while (0)
+#define PCOUNT(slot) do { } while (0)
 #define SUBPHASE_DECL(t0) do { } while (0)
 #endif
 
@@ -458,36 +463,55 @@ __device__ __forceinline__ int compact_nonzero(const double *w, int N, bool dens
 // ------------------------------------------------------------- compaction
 // pos[i] = rank of i among the free variables or -1; idx[0..K) = free indices
 // (increasing, like findall, SSQP.jl:276); idx[N-1-r] = r-th bound index.
+// One workgroup barrier inside: every NT-chunk is balloted first, the per-wave counts of all chunks are exchanged
+// at once (ired[CNT0 + chunk*NW + wave]) and each thread derives its offsets from them.  Also scatters zB:
+// zm[i] = z[i] for bound variables, 0 for free ones (SSQP.jl:286).  The caller's next barrier publishes the lists.
+constexpr int CNT0 = 2 * NW + 16;  // first count slot in ired
+template <int MPT>
 __device__ __forceinline__ int compact_free(const Lds &L, int N) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int base = 0;
-    for (int c0 = 0; c0 < N; c0 += NT) {
-        const int i = c0 + threadIdx.x;
-        const bool f = (i < N) && (L.S[i] == SSQP_IN);
-        const unsigned long long m = __ballot(f);
-        const int lp = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) L.ired[wave] = __popcll(m);
-        __syncthreads();
-        int wb = 0, tot = 0;
+    int lp[MPT];
+    unsigned fm = 0;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const int c = L.ired[w];
-            if (w < wave) wb += c;
-            tot += c;
+    for (int m = 0; m < MPT; ++m) {
+        const int i = m * NT + threadIdx.x;
+        lp[m] = 0;
+        if (m * NT < N) {  // uniform
+            const bool f = (i < N) && (L.S[i < N ? i : 0] == SSQP_IN);
+            const unsigned long long bm = __ballot(f);
+            lp[m] = __popcll(bm & ((1ull << lane) - 1ull));
+            fm |= f ? (1u << m) : 0u;
+            if (lane == 0) L.ired[CNT0 + m * NW + wave] = __popcll(bm);
         }
-        if (i < N) {
-            if (f) {
-                const int p = base + wb + lp;
-                L.pos[i] = (int16_t)p;
-                L.idx[p] = (int16_t)i;
-            } else {
-                L.pos[i] = -1;
-                const int r = i - (base + wb + lp);  // rank among bound variables
-                L.idx[N - 1 - r] = (int16_t)i;
+    }
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int m = 0; m < MPT; ++m) {
+        if (m * NT < N) {
+            int wb = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int c = L.ired[CNT0 + m * NW + w];
+                if (w < wave) wb += c;
+                tot += c;
             }
+            const int i = m * NT + threadIdx.x;
+            if (i < N) {
+                if (fm & (1u << m)) {
+                    const int p = base + wb + lp[m];
+                    L.pos[i] = (int16_t)p;
+                    L.idx[p] = (int16_t)i;
+                    L.zm[i] = 0.0;
+                } else {
+                    L.pos[i] = -1;
+                    const int r = i - (base + wb + lp[m]);  // rank among bound variables
+                    L.idx[N - 1 - r] = (int16_t)i;
+                    L.zm[i] = L.z[i];
+                }
+            }
+            base += tot;
         }
-        base += tot;
-        __syncthreads();
     }
     return base;
 }
@@ -1251,7 +1275,7 @@ __device__ __forceinline__ void inc_alpha(const Inc &I, int K, int W, int W0, co
 // factor sync by ONE wavefront: delete the rows whose variable left F (highest row first), append the new free
 // variables by increasing index.  Returns the new row count, or -1 when an appended pivot is not > 0.
 __device__ __forceinline__ int inc_sync_w0(const Inc &I, int Kf, const Lds &L, const double *__restrict__ V, int N,
-                                           int &nAppended) {
+                                           int K, int &nAppended) {
     const int lane = threadIdx.x & 63;
     nAppended = 0;
     if (Kf < 0) {
@@ -1259,35 +1283,48 @@ __device__ __forceinline__ int inc_sync_w0(const Inc &I, int Kf, const Lds &L, c
         Kf = 0;
         wave_sync();
     }
-    for (int t = 3; t >= 0; --t) {  // row chunks from the top: deleting row p leaves the rows below p in place
+    SUBPHASE_DECL(tscan);
+    for (int t = (Kf - 1) >> 6; t >= 0; --t) {  // row chunks from the top: deleting row p leaves the rows below p in place
         const int r = lane + 64 * t;
         const bool dead = (r < Kf) && (L.S[I.ord[r < Kf ? r : 0]] != SSQP_IN);
         unsigned long long dm = __ballot(dead);
         while (dm) {
             const int pdel = 64 * t + 63 - __clzll(dm);
             dm &= ~(1ull << (pdel - 64 * t));
+            SUBPHASE_DECL(tdel);
             INC_BY_SLOTS(Kf, inc_delete_update<1>(I, Kf, pdel), inc_delete_update<2>(I, Kf, pdel),
                          inc_delete_update<4>(I, Kf, pdel));
+            SUBPHASE(16, tdel);
             INC_BY_SLOTS(Kf, inc_delete_compact<1>(I, Kf, pdel), inc_delete_compact<2>(I, Kf, pdel),
                          inc_delete_compact<4>(I, Kf, pdel));
+            SUBPHASE(17, tdel);
+            PCOUNT(24);
             Kf -= 1;
         }
     }
-    for (int c0 = 0; c0 < N; c0 += 64) {
-        const int i = c0 + lane;
-        const bool f = (i < N) && (L.S[i] == SSQP_IN) && (L.fpos[i] < 0);
+    SUBPHASE(21, tscan);
+    // new free variables: the entries of the free list idx[0..K) (increasing index) that have no row yet
+    for (int c0 = 0; c0 < K; c0 += 64) {
+        const int k = c0 + lane;
+        const int iv = L.idx[k < K ? k : 0];
+        const bool f = (k < K) && (L.fpos[iv] < 0);
         unsigned long long m = __ballot(f);
         while (m) {
             const int b = __ffsll((long long)m) - 1;
             m &= m - 1;
+            const int jn = __builtin_amdgcn_readlane(iv, b);
             bool ok1 = true;
-            INC_BY_SLOTS(Kf, ok1 = inc_append<1>(I, Kf, c0 + b, V, N), ok1 = inc_append<2>(I, Kf, c0 + b, V, N),
-                         ok1 = inc_append<4>(I, Kf, c0 + b, V, N));
+            SUBPHASE_DECL(tapp);
+            INC_BY_SLOTS(Kf, ok1 = inc_append<1>(I, Kf, jn, V, N), ok1 = inc_append<2>(I, Kf, jn, V, N),
+                         ok1 = inc_append<4>(I, Kf, jn, V, N));
+            SUBPHASE(18, tapp);
+            PCOUNT(25);
             if (!ok1) return -1;
             Kf += 1;
             nAppended += 1;
         }
     }
+    SUBPHASE(22, tscan);
     return Kf;
 }
 
@@ -1519,7 +1556,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         if (wave == 0) {
             SUBPHASE_DECL(tw0);
             int nApp = 0;
-            const int Kf = inc_sync_w0(I, C.Kfac, L, V, N, nApp);
+            const int Kf = inc_sync_w0(I, C.Kfac, L, V, N, K, nApp);
             if (lane == 0) {
                 L.ired[2 * NW + 10] = Kf;
                 L.ired[2 * NW + 11] = nApp;
@@ -1571,7 +1608,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         PHASE(C, 13);
         if (wave == 0) {
             int nApp = 0;
-            const int Kf = inc_sync_w0(I, C.Kfac, L, V, N, nApp);
+            const int Kf = inc_sync_w0(I, C.Kfac, L, V, N, K, nApp);
             if (lane == 0) {
                 L.ired[2 * NW + 10] = Kf;
                 L.ired[2 * NW + 11] = nApp;
@@ -1711,6 +1748,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             else H[a + W * b] = acc;
         }
         __syncthreads();
+        SUBPHASE_DECL(tlam);
         if (wave == 0) {  // lambda: H lam = bE + t, alphaL = -lam; W <= 11, in registers
             if (lane < W) L.tv[lane] = L.bE[lane] + L.tv[lane];
             wave_sync();
@@ -1720,6 +1758,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             if (lane == 0) L.ired[2 * NW + 2] = okH ? 1 : 0;
         }
         __syncthreads();
+        SUBPHASE(19, tlam);
         if (!L.ired[2 * NW + 2]) {
             C.ret = -1;
             C.det = SSQP_DETAIL_POSDEF_C;
@@ -1867,6 +1906,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     PHASE(C, 8);
     if (pinf > tolG && !anyNan) {  // ------------------------ aStep!  SSQP.jl:61-134
         // inactive inequalities: zo = g - G z, po = G[:,F] p   (:78-89)
+        SUBPHASE_DECL(tast);
         for (int o = wave; o < JO; o += NW) {
             const int j = L.iO[o];
             const double *__restrict__ row = Ct + (size_t)(M + j) * N;
@@ -1877,6 +1917,8 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             if (lane == 0) L.lin[o] = (ap > tol) ? (rhs[M + j] - az) / ap : inf;
         }
         __syncthreads();
+        SUBPHASE(20, tast);
+        PCOUNT(26);
         KeyMin ev{inf, 0};
         double Lreg[MPT];
 #pragma unroll
@@ -1937,6 +1979,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
 
     // ---- multipliers: gamma = V[B,F] alpha + V[B,B] zB + q[B] + AB' alphaL  (SSQP.jl:352) ----
     PHASE(C, 9);
+    PCOUNT(27);
     for (int i = tid; i < N; i += NT) L.zm[i] = (L.pos[i] >= 0) ? L.gam[i] : L.z[i];
     __syncthreads();
     {
@@ -2140,7 +2183,7 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
             break;
         }
         PHASE(C, 0);
-        const int K = compact_free(L, N);
+        const int K = compact_free<(VEC == 2) ? 2 : ((VEC == 3) ? 4 : MAXPT)>(L, N);
         ssqp_trace *trace = (C.trace && C.iter <= C.ntrace) ? C.trace + (C.iter - 1) : nullptr;
 
         if (K == 0) {  // ---------------------------------------- freeK!  SSQP.jl:35-59
@@ -2202,8 +2245,7 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
                 L.ired[2 * NW + 1] = nO;
             }
         }
-        for (int i = tid; i < N; i += NT) L.zm[i] = (L.pos[i] >= 0) ? 0.0 : L.z[i];  // zB scattered
-        __syncthreads();
+        __syncthreads();  // pos, idx, zm (zB scattered) and the row lists are published
         const int W0 = L.ired[2 * NW], JO = L.ired[2 * NW + 1];
 
         // arena: LDS when [X | packed factor + Schur block] fits, else the global scratch
@@ -2272,13 +2314,13 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
 #ifdef SSQP_PHASE_PROFILE
 }  // namespace ssqp
 extern "C" int ssqp_debug_phases(unsigned long long *out16, int reset) {
-    static unsigned long long host[1024 * 16];
+    static unsigned long long host[1024 * 32];
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(ssqp::g_phase), sizeof(host)) != hipSuccess) return 1;
-    for (int k = 0; k < 16; ++k) out16[k] = 0;
+    for (int k = 0; k < 32; ++k) out16[k] = 0;
     for (int b = 0; b < 1024; ++b)
-        for (int k = 0; k < 16; ++k) out16[k] += host[b * 16 + k];
+        for (int k = 0; k < 32; ++k) out16[k] += host[b * 32 + k];
     if (reset) {
-        static unsigned long long zero[1024 * 16];
+        static unsigned long long zero[1024 * 32];
         if (hipMemcpyToSymbol(HIP_SYMBOL(ssqp::g_phase), zero, sizeof(zero)) != hipSuccess) return 1;
     }
     return 0;

@@ -15,7 +15,7 @@ x0, S0, st = pkg.phase1_batch(prob)
 db = pkg.DeviceBatch(prob, S0, x0)
 lib = pkg._capi.lib()
 lib.ssqp_debug_phases.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 32)()
 db.solve(); db.results()
 lib.ssqp_debug_phases(out, 1)
 db.solve(); res = db.results()
@@ -24,8 +24,14 @@ names = ["compaction+lists", "E-row sweep + Y copy", "rank filter (+barriers)", 
          "forward border          [old: LDL]", "Schur + lambda", "v + back-substitution", "alpha/p/norm", "aStep",
          "gamma pass V[:,nz]", "KKTchk", "load/polish/store", "freeK", "factor sync (del/app)",
          "(sub) rank filter body / old LDL update", "(sub) old LDL panel"]
-tot = sum(out)
+names += ["(sub) delete: rank-1 update", "(sub) delete: compaction", "(sub) append", "(sub) lambda solve", "(sub) aStep G rows",
+          "(sub) sync: delete scan + deletes", "(sub) sync: append scan + appends", "", "#deletes", "#appends", "#aStep", "#gamma passes", "", "", "", ""]
+tot = sum(out[:14])
 iters = int(res["status"].sum())
 print("config", name, "nprob", nprob, "total iterations", iters, "kernel ms", db.ctx.last_kernel_ms())
 for i, n in enumerate(names):
+    if i >= 24:
+        if n: print("%-22s %10d  (%.3f per iteration)" % (n, out[i], out[i] / iters))
+        continue
+    if not n: continue
     print("%-22s %6.2f %%   %8.0f ticks/iter" % (n, 100.0 * out[i] / tot, out[i] / iters))
