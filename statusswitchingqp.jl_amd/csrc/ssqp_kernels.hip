@@ -79,7 +79,16 @@ __device__ unsigned long long g_phase[1024 * 32];
         if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&g_phase[(blockIdx.x & 1023) * 32 + (slot)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
     } while (0)
 #define SUBPHASE_DECL(t0) unsigned long long t0 = __builtin_amdgcn_s_memtime()
+#define WSTAMP(slot, t0)                                                       \
+    do {                                                                       \
+        if ((threadIdx.x & 63) == 0) {                                         \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();        \
+            (void)__hip_atomic_fetch_add(&g_phase[(blockIdx.x & 1023) * 32 + (slot)], t_ - (t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+            (t0) = t_;                                                         \
+        }                                                                      \
+    } while (0)
 #else
+#define WSTAMP(slot, t0) do { } while (0)
 #define PHASE(C, n) do { } while (0)
 #define SUBPHASE(slot, t0) do { } while (0)
 #define PCOUNT(slot) do { } while (0)
@@ -703,60 +712,64 @@ __device__ __forceinline__ int rank_filter_regs(const double *X, int W0, int nc,
             x[cs][k] = (t < nc && k < W0) ? v : 0.0;
         }
     }
-    int i = 0, j = 0, nrows = 0;
-    while (i < W0 && j < nc) {
-        KeyMin best{1.0, 0x7fffffff};
+    // The row loop is unrolled (row i is a compile-time register index); a purged row only advances i, which is
+    // exactly the `i += 1; continue` of utils.jl:61-64.
+    int j = 0, nrows = 0;
 #pragma unroll
-        for (int cs = 0; cs < CS; ++cs) {
-            double xi = 0.0;
+    for (int i = 0; i < ROWS; ++i) {
+        if (i < W0 && j < nc) {  // uniform
+            // this lane's best candidate in row i: largest |x|, ties -> smallest position in c0
+            double am = -1.0;
+            int ap = 0x7fffffff;
 #pragma unroll
-            for (int k = 0; k < ROWS; ++k) xi = (k == i) ? x[cs][k] : xi;
-            const bool in = posn[cs] >= j && posn[cs] < nc;
-            best = keymin(best, KeyMin{in ? -fabs(xi) : 1.0, in ? posn[cs] : 0x7fffffff});
-        }
-        best = wave_keymin(best);
-        const double m = -best.v;
-        const int mpos = best.ord;
-        if (!(m > tol)) {  // utils.jl:61
-            i += 1;
-            continue;
-        }
-        if (lane == 0) L.ra[nrows] = (int16_t)i;
-        nrows += 1;
-        // c0[mj] <-> c0[j]; then the pivot column (now at position j) broadcasts its entries
-        double dcol[ROWS];
+            for (int cs = 0; cs < CS; ++cs) {
+                const bool in = posn[cs] >= j && posn[cs] < nc;
+                const double a = in ? fabs(x[cs][i]) : -1.0;
+                const bool better = (a > am) || (a == am && posn[cs] < ap);
+                am = better ? a : am;
+                ap = better ? posn[cs] : ap;
+            }
+            const double m = wave_max(am);
+            if (m > tol) {  // utils.jl:61 (uniform)
+                // first maximum in c0 order: the tied lane with the smallest position (one lane but for exact ties)
+                unsigned long long tie = __ballot(am == m);
+                int mpos = __builtin_amdgcn_readlane(ap, __ffsll((long long)tie) - 1);
+                tie &= tie - 1;
+                while (tie) {
+                    const int p2 = __builtin_amdgcn_readlane(ap, __ffsll((long long)tie) - 1);
+                    mpos = p2 < mpos ? p2 : mpos;
+                    tie &= tie - 1;
+                }
+                if (lane == 0) L.ra[nrows] = (int16_t)i;
+                nrows += 1;
+                // c0[mj] <-> c0[j]; then the pivot column (now at position j) broadcasts its entries of rows i..
+                double dcol[ROWS];
 #pragma unroll
-        for (int k = 0; k < ROWS; ++k) dcol[k] = 0.0;
+                for (int k = 0; k < ROWS; ++k) dcol[k] = 0.0;
 #pragma unroll
-        for (int cs = 0; cs < CS; ++cs) {
-            const int pz = posn[cs];
-            posn[cs] = (pz == mpos) ? j : ((pz == j) ? mpos : pz);
-            const unsigned long long own = __ballot(posn[cs] == j);
-            const int src = own ? (__ffsll((long long)own) - 1) : 0;
+                for (int cs = 0; cs < CS; ++cs) {
+                    const int pz = posn[cs];
+                    posn[cs] = (pz == mpos) ? j : ((pz == j) ? mpos : pz);
+                    const unsigned long long own = __ballot(posn[cs] == j);
+                    if (own) {  // uniform: the owner lane holds the pivot column in this slot
+                        const int src = __ffsll((long long)own) - 1;
 #pragma unroll
-            for (int k = 0; k < ROWS; ++k) {
-                const double bv = readlane_f64(x[cs][k], src);
-                dcol[k] = own ? bv : dcol[k];
+                        for (int k = i; k < ROWS; ++k) dcol[k] = readlane_f64(x[cs][k], src);
+                    }
+                }
+                const double dd = dcol[i];
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs) {
+                    const bool in = posn[cs] >= j && posn[cs] < nc;
+                    const double xn = x[cs][i] / dd;  // utils.jl:68-70 (IEEE division, like the reference)
+                    x[cs][i] = in ? xn : x[cs][i];
+#pragma unroll
+                    for (int k = i + 1; k < ROWS; ++k)  // utils.jl:71-78, rows below (rows above are never read again)
+                        x[cs][k] = in ? sub_mul_nc(x[cs][k], dcol[k], xn) : x[cs][k];
+                }
+                j += 1;
             }
         }
-        double dd = 0.0;
-#pragma unroll
-        for (int k = 0; k < ROWS; ++k) dd = (k == i) ? dcol[k] : dd;
-#pragma unroll
-        for (int cs = 0; cs < CS; ++cs) {
-            const bool in = posn[cs] >= j && posn[cs] < nc;
-            double xi = 0.0;
-#pragma unroll
-            for (int k = 0; k < ROWS; ++k) xi = (k == i) ? x[cs][k] : xi;
-            const double xn = xi / dd;  // utils.jl:68-70 (IEEE division, like the reference)
-#pragma unroll
-            for (int k = 0; k < ROWS; ++k) {
-                const double upd = (k == i) ? xn : sub_mul_nc(x[cs][k], dcol[k], xn);  // utils.jl:71-78
-                x[cs][k] = in ? upd : x[cs][k];
-            }
-        }
-        i += 1;
-        j += 1;
     }
     wave_sync();
     return nrows;
@@ -1563,10 +1576,13 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             }
             SUBPHASE(14, tw0);
         } else if (wave == 1) {
+            SUBPHASE_DECL(tw1);
             int w = W0;
             if (W0 > 0) {
                 if (W0 <= 4 && K + 1 <= 128) w = rank_filter_regs<4, 2>(X, W0, K + 1, tol, L);
                 else if (W0 <= 4) w = rank_filter_regs<4, 4>(X, W0, K + 1, tol, L);
+                else if (K + 1 <= 64) w = rank_filter_regs<RF_ROWS, 1>(X, W0, K + 1, tol, L);
+                else if (K + 1 <= 128) w = rank_filter_regs<RF_ROWS, 2>(X, W0, K + 1, tol, L);
                 else w = rank_filter_wave(X, W0, K + 1, tol, L);
             }
             if (w < W0) {
@@ -1577,9 +1593,12 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
                 L.ra[lane] = (int16_t)lane;
             }
             if (lane == 0) L.ired[2 * NW + 4] = w;
+            WSTAMP(28, tw1);
         } else {
+            SUBPHASE_DECL(tw2);
             const int cnt = hb_partial<4>(V, N, L.zm, wave - 2, ar);
             if (wave == 2 && lane == 0) L.ired[2 * NW + 12] = cnt;
+            if (wave == 2) WSTAMP(29, tw2);
         }
         __syncthreads();
         PHASE(C, 3);

@@ -25,12 +25,12 @@ names = ["compaction+lists", "E-row sweep + Y copy", "rank filter (+barriers)", 
          "gamma pass V[:,nz]", "KKTchk", "load/polish/store", "freeK", "factor sync (del/app)",
          "(sub) rank filter body / old LDL update", "(sub) old LDL panel"]
 names += ["(sub) delete: rank-1 update", "(sub) delete: compaction", "(sub) append", "(sub) lambda solve", "(sub) aStep G rows",
-          "(sub) sync: delete scan + deletes", "(sub) sync: append scan + appends", "", "#deletes", "#appends", "#aStep", "#gamma passes", "", "", "", ""]
+          "(sub) sync: delete scan + deletes", "(sub) sync: append scan + appends", "", "#deletes", "#appends", "#aStep", "#gamma passes", "(wave 1) rank filter", "(wave 2) hB partial", "", ""]
 tot = sum(out[:14])
 iters = int(res["status"].sum())
 print("config", name, "nprob", nprob, "total iterations", iters, "kernel ms", db.ctx.last_kernel_ms())
 for i, n in enumerate(names):
-    if i >= 24:
+    if 24 <= i < 28:
         if n: print("%-22s %10d  (%.3f per iteration)" % (n, out[i], out[i] / iters))
         continue
     if not n: continue
