@@ -392,6 +392,46 @@ __device__ __forceinline__ void stream_cols(const double *__restrict__ V, int N,
     }
 }
 
+// Up to RPW constraint rows per wavefront with ALL their loads in flight before the first use (one memory round
+// trip per batch instead of one per row): row t of this wavefront is rows[t] (nullptr = none), N even, N <= 512.
+// a1[t] = row . w1, a2[t] = row . w2, accumulated in the order of row_dot2 (lane's pairs r = 2*lane + 128*m).
+template <int RPW>
+__device__ __forceinline__ void rows_dot2_batch(const double *__restrict__ const (&rows)[RPW], const double *w1,
+                                                const double *w2, int N, int lane, double (&a1)[RPW],
+                                                double (&a2)[RPW]) {
+    double2 g[RPW][4];
+#pragma unroll
+    for (int t = 0; t < RPW; ++t) {
+        const double *__restrict__ row = rows[t] ? rows[t] : rows[0];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int r = lane * 2 + 128 * m;
+            g[t][m] = *reinterpret_cast<const double2 *>(row + (r < N ? r : 0));
+        }
+    }
+    double2 x[4], y[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int r = lane * 2 + 128 * m;
+        x[m] = *reinterpret_cast<const double2 *>(w1 + (r < N ? r : 0));
+        y[m] = *reinterpret_cast<const double2 *>(w2 + (r < N ? r : 0));
+    }
+#pragma unroll
+    for (int t = 0; t < RPW; ++t) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int r = lane * 2 + 128 * m;
+            const double n1 = fma(g[t][m].y, x[m].y, fma(g[t][m].x, x[m].x, s1));
+            const double n2 = fma(g[t][m].y, y[m].y, fma(g[t][m].x, y[m].x, s2));
+            s1 = (r < N) ? n1 : s1;
+            s2 = (r < N) ? n2 : s2;
+        }
+        a1[t] = s1;
+        a2[t] = s2;
+    }
+}
+
 // out = V[:, nz] * w[nz] in AXPY form: every lane owns fixed rows (the 16 bytes it loads from each 1 KiB
 // slice of a column) and accumulates them in registers over the columns its wavefront takes; no cross-lane
 // reduction.  Columns whose weight is exactly 0.0 are not in the list `nzl` and are never read (they would
@@ -1544,24 +1584,55 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         (long)2 * N + (long)W0 * (K + 1) + 8 <= C.scrCap) {
         PHASE(C, 1);
         double *X = ar + 2 * N;
-        for (int w = wave; w < W0; w += NW) {  // E-row sweep (SSQP.jl:290-295), rows over the wavefronts
-            const int r = L.rowsE[w];
-            const double *__restrict__ row = Ct + (size_t)r * N;
-            double acc = 0.0;
-#pragma unroll 4
-            for (int i = lane * 2; i < N; i += 128) {
-                const double2 v = *reinterpret_cast<const double2 *>(row + i);
-                const double2 zz = *reinterpret_cast<const double2 *>(L.zm + i);
-                const int p0 = L.pos[i], p1 = L.pos[i + 1];
-                acc = fma(v.y, zz.y, fma(v.x, zz.x, acc));
-                if (p0 >= 0) X[w + W0 * p0] = v.x;
-                if (p1 >= 0) X[w + W0 * p1] = v.y;
+        if (W0 > 0) {  // E-row sweep (SSQP.jl:290-295), rows over the wavefronts, every load of a wavefront's rows in flight
+            // before the first use (W0 <= 12: at most three rows each)
+            constexpr int RPW = (RF_ROWS + NW - 1) / NW;
+            double2 g[RPW][4];
+            double rh[RPW];
+#pragma unroll
+            for (int t = 0; t < RPW; ++t) {
+                const int w = wave + NW * t;
+                const int r = L.rowsE[w < W0 ? w : 0];
+                const double *__restrict__ row = Ct + (size_t)r * N;
+                rh[t] = rhs[r];
+                if (w < W0 || t == 0) {  // uniform
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int i = lane * 2 + 128 * m;
+                        g[t][m] = *reinterpret_cast<const double2 *>(row + (i < N ? i : 0));
+                    }
+                }
             }
-            acc = wave_sum(acc);
-            if (lane == 0) {
-                const double be = rhs[r] - acc;
-                L.bE[w] = be;
-                X[w + W0 * K] = be;
+            double2 zz[4];
+            int p0[4], p1[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int i = lane * 2 + 128 * m;
+                const int ic = i < N ? i : 0;
+                zz[m] = *reinterpret_cast<const double2 *>(L.zm + ic);
+                p0[m] = (i < N) ? (int)L.pos[ic] : -1;
+                p1[m] = (i < N) ? (int)L.pos[ic + 1] : -1;
+            }
+#pragma unroll
+            for (int t = 0; t < RPW; ++t) {
+                const int w = wave + NW * t;
+                if (w < W0) {  // uniform
+                    double acc = 0.0;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int i = lane * 2 + 128 * m;
+                        const double na = fma(g[t][m].y, zz[m].y, fma(g[t][m].x, zz[m].x, acc));
+                        acc = (i < N) ? na : acc;
+                        if (p0[m] >= 0) X[w + W0 * p0[m]] = g[t][m].x;
+                        if (p1[m] >= 0) X[w + W0 * p1[m]] = g[t][m].y;
+                    }
+                    acc = wave_sum(acc);
+                    if (lane == 0) {
+                        const double be = rh[t] - acc;
+                        L.bE[w] = be;
+                        X[w + W0 * K] = be;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -1926,14 +1997,39 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     if (pinf > tolG && !anyNan) {  // ------------------------ aStep!  SSQP.jl:61-134
         // inactive inequalities: zo = g - G z, po = G[:,F] p   (:78-89)
         SUBPHASE_DECL(tast);
-        for (int o = wave; o < JO; o += NW) {
-            const int j = L.iO[o];
-            const double *__restrict__ row = Ct + (size_t)(M + j) * N;
-            double az, ap;
-            row_dot2<VEC>(row, L.z, L.zm, N, lane, az, ap);
-            az = wave_sum(az);
-            ap = wave_sum(ap);
-            if (lane == 0) L.lin[o] = (ap > tol) ? (rhs[M + j] - az) / ap : inf;
+        if (VEC == 2) {
+            constexpr int RPW = 3;  // rows per wavefront and batch
+            for (int o0 = 0; o0 < JO; o0 += NW * RPW) {
+                const double *__restrict__ rows[RPW];
+                double rh[RPW];
+#pragma unroll
+                for (int t = 0; t < RPW; ++t) {
+                    const int o = o0 + wave + NW * t;
+                    const int j = L.iO[o < JO ? o : o0];
+                    rows[t] = (o < JO || t == 0) ? Ct + (size_t)(M + j) * N : nullptr;
+                    rh[t] = rhs[M + j];
+                }
+                double az[RPW], ap[RPW];
+                rows_dot2_batch<RPW>(rows, L.z, L.zm, N, lane, az, ap);
+#pragma unroll
+                for (int t = 0; t < RPW; ++t) {
+                    const int o = o0 + wave + NW * t;
+                    if (o < JO) {  // uniform per wavefront
+                        const double sz = wave_sum(az[t]), sp = wave_sum(ap[t]);
+                        if (lane == 0) L.lin[o] = (sp > tol) ? (rh[t] - sz) / sp : inf;
+                    }
+                }
+            }
+        } else {
+            for (int o = wave; o < JO; o += NW) {
+                const int j = L.iO[o];
+                const double *__restrict__ row = Ct + (size_t)(M + j) * N;
+                double az, ap;
+                row_dot2<VEC>(row, L.z, L.zm, N, lane, az, ap);
+                az = wave_sum(az);
+                ap = wave_sum(ap);
+                if (lane == 0) L.lin[o] = (ap > tol) ? (rhs[M + j] - az) / ap : inf;
+            }
         }
         __syncthreads();
         SUBPHASE(20, tast);
