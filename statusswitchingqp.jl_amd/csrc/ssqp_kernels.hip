@@ -1450,56 +1450,51 @@ __device__ __forceinline__ int hb_partial(const double *__restrict__ V, int N, c
     return seen;
 }
 
-// lambda of the Schur system H lam = s (W <= 11), H symmetric (lower part given), one wavefront:
-// lane i holds row i of H and s_i; eliminations broadcast the pivot row with v_readlane.  Returns false
-// when a pivot is not > 0 (the reference's cholesky(C) throws).  On return lane w < W holds lam_w.
-__device__ __forceinline__ bool small_spd_solve(const double *H, const double *rhs_, int W, double &lam) {
+// lambda of the Schur system H lam = s (W <= WM <= 11), H symmetric (lower part given), one wavefront:
+// lane i holds row i of H and s_i; eliminations broadcast the pivot row with v_readlane.  The unit-lower factor
+// is also written to `tr` (WM*WM doubles of LDS scratch) column by column, so that the back substitution reads
+// column c of L into lane c and needs one broadcast per step instead of one per entry.  Returns false when a
+// pivot is not > 0 (the reference's cholesky(C) throws).  On return lane w < W holds lam_w.
+template <int WM>
+__device__ __forceinline__ bool small_spd_solve(const double *H, const double *rhs_, int W, double &lam, double *tr) {
     const int lane = threadIdx.x & 63;
-    double a[INC_RBM - 1];
+    double a[WM];
 #pragma unroll
-    for (int c = 0; c < INC_RBM - 1; ++c) {
+    for (int c = 0; c < WM; ++c) {
         const int r = lane < W ? lane : 0, cc = c < W ? c : 0;
         const double v = (r >= cc) ? H[r + W * cc] : H[cc + W * r];  // symmetric read from the lower part
         a[c] = (lane < W && c < W) ? v : 0.0;
     }
     double y = (lane < W) ? rhs_[lane] : 0.0;
     bool ok = true;
-    double rdiag[INC_RBM - 1];
 #pragma unroll
-    for (int c = 0; c < INC_RBM - 1; ++c) {
-        rdiag[c] = 0.0;
-        if (c < W) {
+    for (int c = 0; c < WM; ++c) {
+        if (c < W) {  // uniform
             const double d = readlane_f64(a[c], c);
             if (!(d > 0.0)) ok = false;
             const double r = fast_rcp(d);
-            rdiag[c] = r;
             const double yc = readlane_f64(y, c);
-            const double lic = a[c] * r;                 // L(i,c) for this lane's row i
-            if (lane > c) {
-                y = fma(-lic, yc, y);                    // forward substitution rides along
+            const double lic = a[c] * r;  // L(i,c) for this lane's row i
+            const bool below = lane > c;
+            y = below ? fma(-lic, yc, y) : ((lane == c) ? y * r : y);  // forward substitution rides along; D^-1 on row c
 #pragma unroll
-                for (int c2 = c + 1; c2 < INC_RBM - 1; ++c2)
-                    if (c2 < W) a[c2] = fma(-lic, readlane_f64(a[c], c2), a[c2]);
+            for (int c2 = c + 1; c2 < WM; ++c2) {  // (columns beyond W hold zeros: no guard)
+                const double bq = readlane_f64(a[c], c2);
+                a[c2] = below ? fma(-lic, bq, a[c2]) : a[c2];
             }
+            if (below && lane < WM) tr[c * WM + lane] = lic;
         }
     }
-    // y_i now holds (L^-1 s)_i ; x = L'^-1 D^-1 y
+    wave_sync();
+    // y = D^-1 L^-1 s ; x = L'^-1 y with u[i] = L(i, lane)
+    double u[WM];
 #pragma unroll
-    for (int c = 0; c < INC_RBM - 1; ++c)
-        if (c < W && lane == c) y = y * rdiag[c];
+    for (int i = 1; i < WM; ++i) u[i] = tr[(lane < WM ? lane : 0) * WM + i];
 #pragma unroll
-    for (int c = INC_RBM - 2; c >= 1; --c) {
-        if (c < W) {
-            const double xc = readlane_f64(y, c);
-            // L(c, i) for i < c: held by lane c in a[i]; needed by lane i  -> broadcast per i is costly, so
-            // lane i reads it by v_readlane from lane c with its own column index unrolled
-#pragma unroll
-            for (int i2 = 0; i2 < INC_RBM - 2; ++i2) {
-                if (i2 < c) {
-                    const double lci = readlane_f64(a[i2], c) * rdiag[i2];
-                    if (lane == i2) y = fma(-lci, xc, y);
-                }
-            }
+    for (int i = WM - 1; i >= 1; --i) {
+        if (i < W) {  // uniform
+            const double xi = readlane_f64(y, i);
+            y = (lane < i) ? fma(-u[i], xi, y) : y;
         }
     }
     lam = y;
@@ -1814,51 +1809,66 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         __syncthreads();
         PHASE(C, 5);
         // Schur block: H = AE V^-1 AE' (W x W, lower) into the scratch arena, t = AE V^-1 c into tv.
-        // One thread per (a, b) pair walks the K rows: no cross-lane reduction, all pairs in parallel.
+        // Four lanes per (a, b) pair, each walking every fourth of the K rows, then a two-step DPP sum inside
+        // the quad; all pairs in parallel (W <= 11: at most 77 pairs over the 64 quads).
         double *H = ar;
-        for (int e = tid; e < W * (W + 1) / 2 + W; e += NT) {
-            int a, b;
-            if (e < W) {
-                a = W;
-                b = e;
-            } else {
-                int f = e - W, col = 0;
-                while (f >= W - col) {
-                    f -= W - col;
-                    ++col;
+        {
+            const int npairs = W * (W + 1) / 2 + W;
+            const int qd = tid >> 2, ql = tid & 3;
+            for (int e0 = 0; e0 < npairs; e0 += NT / 4) {
+                const int e = (e0 + qd < npairs) ? e0 + qd : 0;
+                int a, b;
+                if (e < W) {
+                    a = W;
+                    b = e;
+                } else {
+                    int f = e - W, col = 0;
+                    while (f >= W - col) {
+                        f -= W - col;
+                        ++col;
+                    }
+                    a = col + f;
+                    b = col;
                 }
-                a = col + f;
-                b = col;
-            }
-            const double *Ya = I.Y + (size_t)L.perm[a] * I.RC, *Yb = I.Y + (size_t)L.perm[b] * I.RC;
-            double acc = 0.0;
+                const double *Ya = I.Y + (size_t)L.perm[a] * I.RC, *Yb = I.Y + (size_t)L.perm[b] * I.RC;
+                double acc = 0.0;
 #pragma unroll 4
-            for (int r = 0; r < K; ++r) acc = fma(Ya[r] * I.rdv[r], Yb[r], acc);
-            if (e < W) L.tv[b] = acc;
-            else H[a + W * b] = acc;
+                for (int r = ql; r < K; r += 4) acc = fma(Ya[r] * I.rdv[r], Yb[r], acc);
+                acc += dpp_f64<DPP_XOR1>(acc);
+                acc += dpp_f64<DPP_XOR2>(acc);
+                if (ql == 0 && e0 + qd < npairs) {
+                    if (e < W) L.tv[b] = acc;
+                    else H[a + W * b] = acc;
+                }
+            }
         }
         __syncthreads();
         SUBPHASE_DECL(tlam);
-        if (wave == 0) {  // lambda: H lam = bE + t, alphaL = -lam; W <= 11, in registers
+        if (wave == 0) {  // lambda: H lam = bE + t, alphaL = -lam (W <= 11, in registers); then alpha, no barrier between
             if (lane < W) L.tv[lane] = L.bE[lane] + L.tv[lane];
             wave_sync();
-            double lam;
-            const bool okH = small_spd_solve(H, L.tv, W, lam);
+            double lam = 0.0;
+            bool okH = true;
+            double *tr = H + W * W;
+            if (W > 8) okH = small_spd_solve<INC_RBM - 1>(H, L.tv, W, lam, tr);
+            else if (W > 4) okH = small_spd_solve<8>(H, L.tv, W, lam, tr);
+            else if (W > 0) okH = small_spd_solve<4>(H, L.tv, W, lam, tr);
             if (lane < W) L.aL[lane] = -lam;
             if (lane == 0) L.ired[2 * NW + 2] = okH ? 1 : 0;
+            wave_sync();
+            SUBPHASE(19, tlam);
+            if (okH)  // v = D^-1 (Y_A alphaL + y_c); alpha = -L'^-1 v
+                INC_BY_SLOTS(K, inc_alpha<1>(I, K, W, W0, L.perm, L.aL, L.gam),
+                             inc_alpha<2>(I, K, W, W0, L.perm, L.aL, L.gam),
+                             inc_alpha<4>(I, K, W, W0, L.perm, L.aL, L.gam));
         }
         __syncthreads();
-        SUBPHASE(19, tlam);
         if (!L.ired[2 * NW + 2]) {
             C.ret = -1;
             C.det = SSQP_DETAIL_POSDEF_C;
             return ACT_BREAK;
         }
         PHASE(C, 6);
-        if (wave == 0)  // v = D^-1 (Y_A alphaL + y_c); alpha = -L'^-1 v
-            INC_BY_SLOTS(K, inc_alpha<1>(I, K, W, W0, L.perm, L.aL, L.gam), inc_alpha<2>(I, K, W, W0, L.perm, L.aL, L.gam),
-                         inc_alpha<4>(I, K, W, W0, L.perm, L.aL, L.gam));
-        __syncthreads();
     } else {
         C.Kfac = -1;  // the from-scratch path overwrites the arena: the kept factor is gone
     // ---- factor assembly: pass 1 over V[:,F] + border rows ----
@@ -2278,6 +2288,7 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
             long scr = (long)NW * N + 64;
             const long x = (long)P.MJ * (rc + 2) + 64;
             if (x > scr) scr = x;
+            if (scr < 2 * INC_RBM * INC_RBM + 64) scr = 2 * INC_RBM * INC_RBM + 64;  // Schur block + its transposed factor
             const long need = scr + (long)INC_RBM * rc + rc + (long)rc * (rc + 1) / 2 + 8;
             if (need <= P.arenaCap) {
                 C.RC = rc;
