@@ -15,9 +15,9 @@ constexpr int NT = 256;          // threads per workgroup (4 wavefronts of 64: o
 constexpr int NW = NT / 64;      // wavefronts per workgroup
 constexpr int MAXPT = 8;         // per-thread slots over the free list
 constexpr int MAXN = NT * MAXPT; // largest N the in-kernel loop accepts (2048)
-// up to 3 workgroups per CU (3 waves per SIMD -> at most 168 VGPRs): one streams V while the others
-// are in their latency-bound phases (factorisation, reductions)
-constexpr int MAX_WG_PER_CU = 3;
+// at most 2 workgroups per CU (2 waves per SIMD -> 256 VGPRs each): one streams V while the other is in its
+// latency-bound phases (factor updates, reductions)
+constexpr int MAX_WG_PER_CU = 2;
 constexpr int LDS_BYTES = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup may use all
 
 struct SolveParams {

@@ -155,6 +155,16 @@ __device__ __forceinline__ double readlane_f64(double v, int srcLane) {
 }
 
 __device__ __forceinline__ double wave_max_uniform(double v) { return wave_max(v); }
+// A value every lane holds identically (read from one LDS address, say) but the compiler cannot prove uniform:
+// pin it to scalar registers, so that everything derived from it (loop bounds, branches, addresses) runs on the
+// scalar unit instead of as per-lane arithmetic under exec masks.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 
 struct KeyMin {  // minimum value, ties -> smallest order
     double v;
@@ -586,7 +596,7 @@ __device__ __forceinline__ int compact_nonzero(const double *w, int N, bool dens
         base += tot;
         __syncthreads();
     }
-    return base;
+    return uni(base);
 }
 
 // out = V * w restricted to the columns with nonzero weight: AXPY form for even N, dot form otherwise
@@ -752,64 +762,67 @@ __device__ __forceinline__ int rank_filter_regs(const double *X, int W0, int nc,
             x[cs][k] = (t < nc && k < W0) ? v : 0.0;
         }
     }
-    // The row loop is unrolled (row i is a compile-time register index); a purged row only advances i, which is
-    // exactly the `i += 1; continue` of utils.jl:61-64.
-    int j = 0, nrows = 0;
+    // The current row always sits in register slot 0: after a row is done (kept or purged, utils.jl:61-64) the
+    // rows below move up one slot.  One compact loop body, no dynamic register index.  Columns that are no
+    // longer candidates (earlier pivot columns, padding) are updated along without predication: nothing reads
+    // them again.
+    int i = 0, j = 0, nrows = 0;
+    while (i < W0 && j < nc) {
+        // this lane's best candidate in the row: largest |x|, ties -> smallest position in c0
+        double am = -1.0;
+        int ap = 0x7fffffff;
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-        if (i < W0 && j < nc) {  // uniform
-            // this lane's best candidate in row i: largest |x|, ties -> smallest position in c0
-            double am = -1.0;
-            int ap = 0x7fffffff;
+        for (int cs = 0; cs < CS; ++cs) {
+            const bool in = posn[cs] >= j && posn[cs] < nc;
+            const double a = in ? fabs(x[cs][0]) : -1.0;
+            const bool better = (a > am) || (a == am && posn[cs] < ap);
+            am = better ? a : am;
+            ap = better ? posn[cs] : ap;
+        }
+        const double m = wave_max(am);
+        if (m > tol) {  // utils.jl:61 (uniform)
+            // first maximum in c0 order: the tied lane with the smallest position (one lane but for exact ties)
+            unsigned long long tie = __ballot(am == m);
+            int mpos = __builtin_amdgcn_readlane(ap, __ffsll((long long)tie) - 1);
+            tie &= tie - 1;
+            while (tie) {
+                const int p2 = __builtin_amdgcn_readlane(ap, __ffsll((long long)tie) - 1);
+                mpos = p2 < mpos ? p2 : mpos;
+                tie &= tie - 1;
+            }
+            if (lane == 0) L.ra[nrows] = (int16_t)i;
+            nrows += 1;
+            // c0[mj] <-> c0[j]; then the pivot column (now at position j) broadcasts its entries of this row and below
+            double dcol[ROWS];
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k) dcol[k] = 0.0;
 #pragma unroll
             for (int cs = 0; cs < CS; ++cs) {
-                const bool in = posn[cs] >= j && posn[cs] < nc;
-                const double a = in ? fabs(x[cs][i]) : -1.0;
-                const bool better = (a > am) || (a == am && posn[cs] < ap);
-                am = better ? a : am;
-                ap = better ? posn[cs] : ap;
+                const int pz = posn[cs];
+                posn[cs] = (pz == mpos) ? j : ((pz == j) ? mpos : pz);
+                const unsigned long long own = __ballot(posn[cs] == j);
+                if (own) {  // uniform: the owner lane holds the pivot column in this slot
+                    const int src = __ffsll((long long)own) - 1;
+#pragma unroll
+                    for (int k = 0; k < ROWS; ++k) dcol[k] = readlane_f64(x[cs][k], src);
+                }
             }
-            const double m = wave_max(am);
-            if (m > tol) {  // utils.jl:61 (uniform)
-                // first maximum in c0 order: the tied lane with the smallest position (one lane but for exact ties)
-                unsigned long long tie = __ballot(am == m);
-                int mpos = __builtin_amdgcn_readlane(ap, __ffsll((long long)tie) - 1);
-                tie &= tie - 1;
-                while (tie) {
-                    const int p2 = __builtin_amdgcn_readlane(ap, __ffsll((long long)tie) - 1);
-                    mpos = p2 < mpos ? p2 : mpos;
-                    tie &= tie - 1;
-                }
-                if (lane == 0) L.ra[nrows] = (int16_t)i;
-                nrows += 1;
-                // c0[mj] <-> c0[j]; then the pivot column (now at position j) broadcasts its entries of rows i..
-                double dcol[ROWS];
 #pragma unroll
-                for (int k = 0; k < ROWS; ++k) dcol[k] = 0.0;
+            for (int cs = 0; cs < CS; ++cs) {
+                const double xn = x[cs][0] / dcol[0];  // utils.jl:68-70 (IEEE division, like the reference)
 #pragma unroll
-                for (int cs = 0; cs < CS; ++cs) {
-                    const int pz = posn[cs];
-                    posn[cs] = (pz == mpos) ? j : ((pz == j) ? mpos : pz);
-                    const unsigned long long own = __ballot(posn[cs] == j);
-                    if (own) {  // uniform: the owner lane holds the pivot column in this slot
-                        const int src = __ffsll((long long)own) - 1;
-#pragma unroll
-                        for (int k = i; k < ROWS; ++k) dcol[k] = readlane_f64(x[cs][k], src);
-                    }
-                }
-                const double dd = dcol[i];
-#pragma unroll
-                for (int cs = 0; cs < CS; ++cs) {
-                    const bool in = posn[cs] >= j && posn[cs] < nc;
-                    const double xn = x[cs][i] / dd;  // utils.jl:68-70 (IEEE division, like the reference)
-                    x[cs][i] = in ? xn : x[cs][i];
-#pragma unroll
-                    for (int k = i + 1; k < ROWS; ++k)  // utils.jl:71-78, rows below (rows above are never read again)
-                        x[cs][k] = in ? sub_mul_nc(x[cs][k], dcol[k], xn) : x[cs][k];
-                }
-                j += 1;
+                for (int k = 1; k < ROWS; ++k)  // utils.jl:71-78, rows below (rows above are never read again)
+                    x[cs][k] = sub_mul_nc(x[cs][k], dcol[k], xn);
             }
+            j += 1;
         }
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) {
+#pragma unroll
+            for (int k = 0; k + 1 < ROWS; ++k) x[cs][k] = x[cs][k + 1];
+            x[cs][ROWS - 1] = 0.0;
+        }
+        i += 1;
     }
     wave_sync();
     return nrows;
@@ -1051,6 +1064,27 @@ __device__ __forceinline__ double row_bcast(const double (&sl)[SL], int r) {
 // SL = register slots in use: 1 when K <= 64 (the common case), 2 up to 128, 4 up to 256.  The factor pointers
 // may be LDS (K up to RC rows fit the arena) or the workgroup's global arena (larger K); the code is the same.
 
+// Four columns c0..c0+3 of the kept factor for this lane's rows (entries on or above the diagonal and beyond row K
+// read as 0, so a step can run unpredicated): all loads issued together; callers prefetch the next block while
+// they work on the current one, so one LDS latency is paid per four elimination steps instead of per step.
+template <int SL>
+__device__ __forceinline__ void inc_load_cols4(const Inc &I, int K, int c0, double (&l)[4][SL]) {
+    const int lane = threadIdx.x & 63;
+    const int RC = I.RC;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = (c0 + u < K) ? c0 + u : (K > 0 ? K - 1 : 0);
+        const int oc = cofs(c, RC) - c;
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + 64 * t;
+            const bool below = (r > c && r < K && c0 + u < K);
+            const double v = I.fcol[oc + (below ? r : c)];
+            l[u][t] = below ? v : 0.0;
+        }
+    }
+}
+
 // Append variable j as row K (one wavefront).  Returns false when the new pivot is not > 0.
 template <int SL>
 __device__ __forceinline__ bool inc_append(const Inc &I, int K, int j, const double *__restrict__ V, int N) {
@@ -1064,20 +1098,23 @@ __device__ __forceinline__ bool inc_append(const Inc &I, int K, int j, const dou
         const int r = lane + 64 * t;
         y[t] = (r < K) ? col[I.ord[r < K ? r : 0]] : 0.0;
     }
-#pragma unroll 4
-    for (int c = 0; c < K; ++c) {
-        const int oc = cofs(c, RC) - c;
-        double l[SL];
+    {
+        double lc[4][SL], ln[4][SL];
+        inc_load_cols4<SL>(I, K, 0, lc);
+        for (int c0 = 0; c0 < K; c0 += 4) {
+            inc_load_cols4<SL>(I, K, c0 + 4, ln);
 #pragma unroll
-        for (int t = 0; t < SL; ++t) {
-            const int r = lane + 64 * t;
-            l[t] = I.fcol[oc + ((r > c && r < K) ? r : c)];
-        }
-        const double yc = row_bcast<SL>(y, c);
+            for (int u = 0; u < 4; ++u) {
+                if (c0 + u < K) {  // uniform
+                    const double yc = row_bcast<SL>(y, c0 + u);
 #pragma unroll
-        for (int t = 0; t < SL; ++t) {
-            const int r = lane + 64 * t;
-            y[t] = (r > c && r < K) ? fma(-l[t], yc, y[t]) : y[t];
+                    for (int t = 0; t < SL; ++t) y[t] = fma(-lc[u][t], yc, y[t]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < SL; ++t) lc[u][t] = ln[u][t];
         }
     }
     double part = 0.0;
@@ -1227,23 +1264,27 @@ __device__ __forceinline__ void inc_forward_border(const Inc &I, int K, int nrhs
             ya[t] = (r < K) ? Y0[r] : 0.0;
             yb[t] = (r < K) ? Y1[r] : 0.0;
         }
-#pragma unroll 4
-        for (int c = 0; c < K; ++c) {
-            const int oc = cofs(c, RC) - c;
-            double l[SL];
+        {
+            double lc[4][SL], ln[4][SL];
+            inc_load_cols4<SL>(I, K, 0, lc);
+            for (int c0 = 0; c0 < K; c0 += 4) {
+                inc_load_cols4<SL>(I, K, c0 + 4, ln);
 #pragma unroll
-            for (int t = 0; t < SL; ++t) {
-                const int r = lane + 64 * t;
-                l[t] = I.fcol[oc + ((r > c && r < K) ? r : c)];
-            }
-            const double ca = row_bcast<SL>(ya, c);
-            const double cb = row_bcast<SL>(yb, c);
+                for (int u = 0; u < 4; ++u) {
+                    if (c0 + u < K) {  // uniform
+                        const double ca = row_bcast<SL>(ya, c0 + u);
+                        const double cb = row_bcast<SL>(yb, c0 + u);
 #pragma unroll
-            for (int t = 0; t < SL; ++t) {
-                const int r = lane + 64 * t;
-                const bool u = r > c && r < K;
-                ya[t] = u ? fma(-l[t], ca, ya[t]) : ya[t];
-                yb[t] = u ? fma(-l[t], cb, yb[t]) : yb[t];
+                        for (int t = 0; t < SL; ++t) {
+                            ya[t] = fma(-lc[u][t], ca, ya[t]);
+                            yb[t] = fma(-lc[u][t], cb, yb[t]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < SL; ++t) lc[u][t] = ln[u][t];
             }
         }
 #pragma unroll
@@ -1266,20 +1307,36 @@ __device__ __forceinline__ void inc_backward(const Inc &I, int K, double (&v)[SL
         const int c = lane + 64 * t;
         o[t] = cofs(c < K ? c : 0, RC) - (c < K ? c : 0);
     }
-#pragma unroll 4
-    for (int r = K - 1; r > 0; --r) {
-        double l[SL];
+    // rows K-1 .. 1 in blocks of four, the next block's entries L(r, c) in flight while this one is applied
+    auto load4 = [&](int r0, double (&l)[4][SL]) {
 #pragma unroll
-        for (int t = 0; t < SL; ++t) {
-            const int c = lane + 64 * t;
-            l[t] = I.fcol[o[t] + (c < r ? r : (c < K ? c : 0))];  // L(r, c): row r of column c
-        }
-        const double xr = row_bcast<SL>(v, r);
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 - u;
 #pragma unroll
-        for (int t = 0; t < SL; ++t) {
-            const int c = lane + 64 * t;
-            v[t] = (c < r) ? fma(-l[t], xr, v[t]) : v[t];
+            for (int t = 0; t < SL; ++t) {
+                const int c = lane + 64 * t;
+                const bool live = (r > 0) && (c < r);
+                const double x = I.fcol[o[t] + (live ? r : (c < K ? c : 0))];  // L(r, c): row r of column c
+                l[u][t] = live ? x : 0.0;
+            }
         }
+    };
+    double lc[4][SL], ln[4][SL];
+    load4(K - 1, lc);
+    for (int r0 = K - 1; r0 > 0; r0 -= 4) {
+        load4(r0 - 4, ln);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (r0 - u > 0) {  // uniform
+                const double xr = row_bcast<SL>(v, r0 - u);
+#pragma unroll
+                for (int t = 0; t < SL; ++t) v[t] = fma(-lc[u][t], xr, v[t]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < SL; ++t) lc[u][t] = ln[u][t];
     }
 }
 
@@ -1478,9 +1535,11 @@ __device__ __forceinline__ bool small_spd_solve(const double *H, const double *r
             const bool below = lane > c;
             y = below ? fma(-lic, yc, y) : ((lane == c) ? y * r : y);  // forward substitution rides along; D^-1 on row c
 #pragma unroll
-            for (int c2 = c + 1; c2 < WM; ++c2) {  // (columns beyond W hold zeros: no guard)
-                const double bq = readlane_f64(a[c], c2);
-                a[c2] = below ? fma(-lic, bq, a[c2]) : a[c2];
+            for (int c2 = 0; c2 < WM; ++c2) {  // (columns beyond W hold zeros: no guard on W)
+                if (c2 > c) {
+                    const double bq = readlane_f64(a[c], c2);
+                    a[c2] = below ? fma(-lic, bq, a[c2]) : a[c2];
+                }
             }
             if (below && lane < WM) tr[c * WM + lane] = lic;
         }
@@ -1668,7 +1727,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         }
         __syncthreads();
         PHASE(C, 3);
-        const int Kf = L.ired[2 * NW + 10];
+        const int Kf = uni(L.ired[2 * NW + 10]);
         C.Kfac = Kf;
         if (Kf < 0) {  // cholesky(V[F,F]) of the reference would throw here
             C.ret = -1;
@@ -1700,7 +1759,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             }
         }
         __syncthreads();
-        C.Kfac = L.ired[2 * NW + 10];
+        C.Kfac = uni(L.ired[2 * NW + 10]);
         C.sRead += 64ll * L.ired[2 * NW + 11] * K;  // the K scattered entries of each appended column
         if (C.Kfac < 0) {  // cholesky(V[F,F]) of the reference would throw here
             C.ret = -1;
@@ -2609,10 +2668,11 @@ static hipError_t launch_one(const SolveParams &P, int grid, size_t ldsBytes, hi
 hipError_t launch_solve(const SolveParams &P, int grid, size_t ldsBytes, int wgPerCU, hipStream_t stream) {
     // load/accumulate mode: see stream_matvec
     const int mode = (P.N & 1) ? 1 : (P.N <= 512 ? 2 : (P.N <= 1024 ? 3 : 4));
-    const bool three = wgPerCU >= 3;
+    // (register budget of two workgroups per CU; three were measured slower -- 168 VGPRs spill -- and are not built)
+    (void)wgPerCU;
     switch (mode) {
-        case 1: return three ? launch_one<1, 3>(P, grid, ldsBytes, stream) : launch_one<1, 2>(P, grid, ldsBytes, stream);
-        case 2: return three ? launch_one<2, 3>(P, grid, ldsBytes, stream) : launch_one<2, 2>(P, grid, ldsBytes, stream);
+        case 1: return launch_one<1, 2>(P, grid, ldsBytes, stream);
+        case 2: return launch_one<2, 2>(P, grid, ldsBytes, stream);
         case 3: return launch_one<3, 1>(P, grid, ldsBytes, stream);  // N > 512: one workgroup per CU, up to 512 VGPRs
         default: return launch_one<4, 1>(P, grid, ldsBytes, stream);
     }
