@@ -47,7 +47,7 @@ struct SolveParams {
 // Offsets of the LDS carve-up.  Double-typed regions first (offsets in
 // doubles), then the integer regions (offsets in bytes).
 struct LdsLayout {
-    int z, zm, gam, arena, bE, aL, tv, dcol, lin, red;  // in doubles
+    int z, zm, gam, hq, arena, bE, aL, tv, dcol, lin, red;  // in doubles
     int S_bytes, ired_bytes, pos_bytes, idx_bytes, perm_bytes, rowsE_bytes, ra_bytes, iO_bytes, fpos_bytes, ordl_bytes;
     int total_bytes;
 };
@@ -57,7 +57,7 @@ __host__ __device__ inline int align_up(int x, int a) { return (x + a - 1) / a *
 // bytes of everything except the arena
 __host__ __device__ inline int lds_fixed_bytes(int N, int M, int J) {
     const int MJ1 = align_up(M + J + 1, 2);
-    int dbl = 3 * align_up(N, 2) + 5 * MJ1 + 2 * NW;
+    int dbl = 4 * align_up(N, 2) + 5 * MJ1 + 2 * NW;  // z, zm, gam, hq | bE, aL, tv, dcol, lin | red
     int bytes = dbl * 8;
     bytes += align_up(4 * (N + J), 8);           // S
     bytes += align_up(4 * (2 * NW + 16 + NW * MAXPT), 8);  // ired (+ per-chunk wave counts of the compaction)
@@ -74,6 +74,7 @@ __host__ __device__ inline LdsLayout lds_layout(int N, int M, int J, int arenaCa
     l.z = o; o += Np;
     l.zm = o; o += Np;
     l.gam = o; o += Np;
+    l.hq = o; o += Np;
     l.bE = o; o += MJ1;
     l.aL = o; o += MJ1;
     l.tv = o; o += MJ1;

@@ -202,6 +202,7 @@ __device__ __forceinline__ KeyMin wave_keymin(KeyMin a) {
 
 struct Lds {
     double *z, *zm, *gam, *arena;
+    double *hq;                          // cached hB + q (see the front half of iterate_kkt)
     double *bE, *aL, *tv, *dcol, *lin;  // MJ+1 each
     double *red;                         // 2*NW
     int32_t *S;
@@ -458,7 +459,8 @@ struct AxpyExt {
 
 template <int NCH, int NCOL>
 __device__ __forceinline__ void stream_axpy(const double *__restrict__ V, int N, const int16_t *nzl, int nnz,
-                                            const double *w, double *stage, double *out, const AxpyExt &X_) {
+                                            const double *w, double *stage, double *out, const AxpyExt &X_,
+                                            const double *addend = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double2 acc[NCH];
 #pragma unroll
@@ -512,6 +514,7 @@ __device__ __forceinline__ void stream_axpy(const double *__restrict__ V, int N,
         double s = stage[i];
 #pragma unroll
         for (int wv = 1; wv < NW; ++wv) s += stage[(size_t)wv * N + i];
+        if (addend) s += addend[i];
         out[i] = s;
     }
 }
@@ -526,6 +529,7 @@ __device__ __forceinline__ int compact_nonzero(const double *w, int N, bool dens
 // at once (ired[CNT0 + chunk*NW + wave]) and each thread derives its offsets from them.  Also scatters zB:
 // zm[i] = z[i] for bound variables, 0 for free ones (SSQP.jl:286).  The caller's next barrier publishes the lists.
 constexpr int CNT0 = 2 * NW + 16;  // first count slot in ired
+constexpr int HB_DIRTY = 2 * NW + 13;  // ired slot: a bound variable with z != 0 changed status since hq was formed
 template <int MPT>
 __device__ __forceinline__ int compact_free(const Lds &L, int N) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1585,6 +1589,7 @@ struct ProbCtx {
     int RC;       // factor capacity (0: engine disabled for this problem shape)
     int yOff, rdvOff, facOff;  // offsets (doubles) of Y, 1/d and the factor in their arena
     int scrCap;                // doubles of scratch in front of them (LDS arena)
+    bool hbValid;              // L.hq holds hB + q of the current bound set (front half)
     bool facGlobal;            // engine state (factor, 1/d, Y) lives in the workgroup's GLOBAL arena (K grew past the LDS capacity)
 #ifdef SSQP_PHASE_PROFILE
     unsigned long long ph_last;
@@ -1637,6 +1642,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     if (useInc && VEC == 2 && W0 <= RF_ROWS && (W0 <= 4 ? K + 1 <= 256 : K + 1 <= 192) &&
         (long)2 * N + (long)W0 * (K + 1) + 8 <= C.scrCap) {
         PHASE(C, 1);
+        const bool needHB = C.dense || !C.hbValid || (L.ired[HB_DIRTY] != 0);
         double *X = ar + 2 * N;
         if (W0 > 0) {  // E-row sweep (SSQP.jl:290-295), rows over the wavefronts, every load of a wavefront's rows in flight
             // before the first use (W0 <= 12: at most three rows each)
@@ -1721,7 +1727,10 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             WSTAMP(28, tw1);
         } else {
             SUBPHASE_DECL(tw2);
-            const int cnt = hb_partial<4>(V, N, L.zm, wave - 2, ar);
+            // hB = V[:, nz(zB)] zB only changes when a bound variable with z != 0 enters or leaves B: otherwise the
+            // cached hq = hB + q of the last evaluation is reused (same bits: same inputs, same operations)
+            int cnt = 0;
+            if (needHB) cnt = hb_partial<4>(V, N, L.zm, wave - 2, ar);
             if (wave == 2 && lane == 0) L.ired[2 * NW + 12] = cnt;
             if (wave == 2) WSTAMP(29, tw2);
         }
@@ -1736,14 +1745,22 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         }
         Wspec = L.ired[2 * NW + 4];
         C.sRead += 64ll * L.ired[2 * NW + 11] * K + 8ll * N * L.ired[2 * NW + 12] - 8ll * N * K;
-        for (int e = tid; e < W0 * K; e += NT) {  // border right-hand sides AE' in factor order (X may be consumed
-            const int w = e / K, r = e - w * K;     //  by the rank filter: re-gather from the constraint rows)
-            I.Y[(size_t)w * I.RC + r] = Ct[(size_t)L.rowsE[w] * N + I.ord[r]];
+        // border right-hand sides AE' in factor order: from X in LDS when the register rank filter left it intact,
+        // else (the LDS filter eliminated in place) gathered again from the constraint rows
+        const bool xKept = !(W0 > 4 && K + 1 > 128);
+        for (int e = tid; e < W0 * K; e += NT) {
+            const int w = e / K, r = e - w * K;
+            const int iv = I.ord[r];
+            I.Y[(size_t)w * I.RC + r] = xKept ? X[w + W0 * (int)L.pos[iv]] : Ct[(size_t)L.rowsE[w] * N + iv];
         }
-        for (int r = tid; r < K; r += NT) {  // c = hB[F] + q[F]; hB = sum of the two partial vectors, only F is needed
+        for (int r = tid; r < K; r += NT) {  // c = hB[F] + q[F]; hB = sum of the two partial vectors
             const int i = I.ord[r];
-            I.Y[(size_t)W0 * I.RC + r] = (ar[i] + ar[N + i]) + q[i];
+            I.Y[(size_t)W0 * I.RC + r] = needHB ? (ar[i] + ar[N + i]) + q[i] : L.hq[i];
         }
+        if (needHB)
+            for (int i = tid; i < N; i += NT) L.hq[i] = (ar[i] + ar[N + i]) + q[i];
+        if (tid == 0) L.ired[HB_DIRTY] = 0;
+        C.hbValid = true;
         if (tid <= Wspec) L.perm[tid] = (tid < Wspec) ? L.ra[tid] : (int16_t)W0;  // physical right-hand sides
         __syncthreads();
         frontDone = true;
@@ -2135,6 +2152,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
                         L.S[i] = up ? SSQP_UP : SSQP_DN;
                         zn = up ? uhi[i] : dlo[i];
                         firstId = min(firstId, i + 1);
+                        if (zn != 0.0) L.ired[HB_DIRTY] = 1;  // B gains a column with a nonzero weight
                     }
                     L.z[i] = zn;
                 }
@@ -2164,6 +2182,17 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     // ---- multipliers: gamma = V[B,F] alpha + V[B,B] zB + q[B] + AB' alphaL  (SSQP.jl:352) ----
     PHASE(C, 9);
     PCOUNT(27);
+    if (VEC == 2 && frontDone && !C.dense) {
+        // gamma = V[:,F] alpha + AB'alphaL (AXPY over the K free columns and the W kept constraint rows) + hq, the
+        // cached hB + q of this pass: the columns of the bound variables are not read a second time
+        for (int i = tid; i < N; i += NT) L.zm[i] = (L.pos[i] >= 0) ? L.gam[i] : 0.0;
+        for (int t = tid; t < K + W; t += NT) L.perm[t] = (t < K) ? L.idx[t] : (int16_t)(N + (t - K));
+        __syncthreads();
+        double *stage = (INLDS && (long)NW * N <= C.arenaCap) ? ar : C.garena;
+        const AxpyExt ext{Ct, q, L.aL, L.rowsE, L.ra, W};
+        stream_axpy<4, 4>(V, N, L.perm, K + W, L.zm, stage, L.gam, ext, L.hq);
+        C.sRead += 8ll * N * (K + W);
+    } else {
     for (int i = tid; i < N; i += NT) L.zm[i] = (L.pos[i] >= 0) ? L.gam[i] : L.z[i];
     __syncthreads();
     {
@@ -2174,6 +2203,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         const AxpyExt ext{Ct, q, L.aL, L.rowsE, L.ra, W};
         const int ncols = stream_matvec<VEC>(V, N, L.zm, C.dense, stage, L.gam, L, ext);
         C.sRead += 8ll * N * ncols;
+    }
     }
     __syncthreads();
     C.sBytes += 8ll * R * R;
@@ -2269,6 +2299,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     if (ev.v < inf) {  // release the single tightest one (:175-184)
         if (tid == 0) {
             L.S[ev.ord] = (ev.ord < N) ? SSQP_IN : SSQP_OE;
+            if (ev.ord < N && L.z[ev.ord < N ? ev.ord : 0] != 0.0) L.ired[HB_DIRTY] = 1;  // B loses a nonzero column
             if (trace) *trace = ssqp_trace{K, W, 2, ev.ord + 1};
         }
         __syncthreads();
@@ -2341,6 +2372,8 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
     C.yOff = C.rdvOff = C.facOff = 0;
     C.scrCap = P.arenaCap;
     C.facGlobal = false;
+    C.hbValid = false;
+    if (tid == 0) L.ired[HB_DIRTY] = 0;
     if (P.incremental) {
         int rc = INC_KMAX;
         for (; rc >= 16; rc -= 2) {
@@ -2405,6 +2438,7 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
             }
             for (int i = tid; i < N; i += NT)
                 if (L.pos[i] == -2) L.S[i] = SSQP_IN;
+            if (tid == 0) L.ired[HB_DIRTY] = 1;
             if (trace && tid == 0) *trace = ssqp_trace{0, 0, 0, 0};
             __syncthreads();
             continue;
@@ -2524,6 +2558,7 @@ __global__ __launch_bounds__(NT, WPS) void ssqp_solve_kernel(SolveParams P) {
         L.z = d0 + lay.z;
         L.zm = d0 + lay.zm;
         L.gam = d0 + lay.gam;
+        L.hq = d0 + lay.hq;
         L.arena = d0 + lay.arena;
         L.bE = d0 + lay.bE;
         L.aL = d0 + lay.aL;
