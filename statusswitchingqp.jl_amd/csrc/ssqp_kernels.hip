@@ -1250,23 +1250,25 @@ __device__ __forceinline__ void inc_delete_compact(const Inc &I, int K, int p) {
     wave_sync();
 }
 
-// Forward substitution L y = b for the border right-hand sides, in place in I.Y.  Right-hand sides are taken two
-// at a time by the wavefronts (k, k+NW by wavefront k & (NW-1)): no exchange between wavefronts.
-template <int SL>
+// Forward substitution L y = b for the border right-hand sides, in place in I.Y.  Right-hand sides are taken NR
+// at a time by the wavefronts (k, k+NW, ... by wavefront k & (NW-1)): no exchange between wavefronts; with up to
+// 12 right-hand sides NR = 3 finishes them in one sweep over the factor.
+template <int SL, int NR>
 __device__ __forceinline__ void inc_forward_border(const Inc &I, int K, int nrhs, const int16_t *phys) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int RC = I.RC;
-    for (int b0 = wave; b0 < nrhs; b0 += 2 * NW) {
-        const int b1 = b0 + NW;
-        const bool two = b1 < nrhs;
-        double *Y0 = I.Y + (size_t)phys[b0] * RC;
-        double *Y1 = I.Y + (size_t)phys[two ? b1 : b0] * RC;
-        double ya[SL], yb[SL];
+    for (int b0 = wave; b0 < nrhs; b0 += NR * NW) {
+        double *Yp[NR];
+        double y[NR][SL];
 #pragma unroll
-        for (int t = 0; t < SL; ++t) {
-            const int r = lane + 64 * t;
-            ya[t] = (r < K) ? Y0[r] : 0.0;
-            yb[t] = (r < K) ? Y1[r] : 0.0;
+        for (int q = 0; q < NR; ++q) {
+            const int b = b0 + NW * q;
+            Yp[q] = I.Y + (size_t)phys[b < nrhs ? b : b0] * RC;
+#pragma unroll
+            for (int t = 0; t < SL; ++t) {
+                const int r = lane + 64 * t;
+                y[q][t] = (r < K) ? Yp[q][r] : 0.0;
+            }
         }
         {
             double lc[4][SL], ln[4][SL];
@@ -1276,13 +1278,13 @@ __device__ __forceinline__ void inc_forward_border(const Inc &I, int K, int nrhs
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (c0 + u < K) {  // uniform
-                        const double ca = row_bcast<SL>(ya, c0 + u);
-                        const double cb = row_bcast<SL>(yb, c0 + u);
+                        double cq[NR];
 #pragma unroll
-                        for (int t = 0; t < SL; ++t) {
-                            ya[t] = fma(-lc[u][t], ca, ya[t]);
-                            yb[t] = fma(-lc[u][t], cb, yb[t]);
-                        }
+                        for (int q = 0; q < NR; ++q) cq[q] = row_bcast<SL>(y[q], c0 + u);
+#pragma unroll
+                        for (int q = 0; q < NR; ++q)
+#pragma unroll
+                            for (int t = 0; t < SL; ++t) y[q][t] = fma(-lc[u][t], cq[q], y[q][t]);
                     }
                 }
 #pragma unroll
@@ -1292,10 +1294,15 @@ __device__ __forceinline__ void inc_forward_border(const Inc &I, int K, int nrhs
             }
         }
 #pragma unroll
-        for (int t = 0; t < SL; ++t) {
-            const int r = lane + 64 * t;
-            if (r < K) Y0[r] = ya[t];
-            if (two && r < K) Y1[r] = yb[t];
+        for (int q = 0; q < NR; ++q) {
+            const int b = b0 + NW * q;
+            if (b < nrhs) {  // uniform per wavefront
+#pragma unroll
+                for (int t = 0; t < SL; ++t) {
+                    const int r = lane + 64 * t;
+                    if (r < K) Yp[q][r] = y[q][t];
+                }
+            }
         }
     }
 }
@@ -1356,13 +1363,28 @@ __device__ __forceinline__ void inc_alpha(const Inc &I, int K, int W, int W0, co
         const int r = lane + 64 * t;
         v[t] = (r < K) ? Yc[r] : 0.0;
     }
-    for (int w = 0; w < W; ++w) {
-        const double *Yw = I.Y + (size_t)phys[w] * I.RC;
-        const double aw = aL[w];
+    for (int w0 = 0; w0 < W; w0 += 4) {  // four border columns per trip, their loads issued together
+        double yw[4][SL], aw[4];
 #pragma unroll
-        for (int t = 0; t < SL; ++t) {
-            const int r = lane + 64 * t;
-            if (r < K) v[t] = fma(Yw[r], aw, v[t]);
+        for (int u = 0; u < 4; ++u) {
+            const int w = (w0 + u < W) ? w0 + u : w0;
+            const double *Yw = I.Y + (size_t)phys[w] * I.RC;
+            aw[u] = aL[w];
+#pragma unroll
+            for (int t = 0; t < SL; ++t) {
+                const int r = lane + 64 * t;
+                yw[u][t] = Yw[r < K ? r : 0];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (w0 + u < W) {  // uniform
+#pragma unroll
+                for (int t = 0; t < SL; ++t) {
+                    const int r = lane + 64 * t;
+                    v[t] = (r < K) ? fma(yw[u][t], aw[u], v[t]) : v[t];
+                }
+            }
         }
     }
 #pragma unroll
@@ -1622,6 +1644,16 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     const int64_t iter = C.iter;
     ssqp_trace *trace = (C.trace && iter <= C.ntrace) ? C.trace + (iter - 1) : nullptr;
 
+    // bounds of this thread's free variables for the ratio test: requested now, needed only in aStep! -- the
+    // gather's memory latency is hidden behind the whole KKT solve
+    double ureg[MPT], dreg[MPT];
+#pragma unroll
+    for (int m = 0; m < MPT; ++m) {
+        const int k = tid + m * NT;
+        const int i = L.idx[k < K ? k : 0];
+        ureg[m] = uhi[i];
+        dreg[m] = dlo[i];
+    }
     // ---- incremental engine: bring the kept factor in line with the current free set ----
     bool useInc = false;
     if (INLDS) useInc = (C.RC > 0) && (K <= C.RC) && (W0 + 1 <= INC_RBM);
@@ -1880,8 +1912,14 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             __syncthreads();
         }
         PHASE(C, 4);
-        INC_BY_SLOTS(K, inc_forward_border<1>(I, K, W + 1, L.perm), inc_forward_border<2>(I, K, W + 1, L.perm),
-                     inc_forward_border<4>(I, K, W + 1, L.perm));
+        if (K <= 64) {
+            if (W + 1 > 2 * NW) inc_forward_border<1, 3>(I, K, W + 1, L.perm);
+            else inc_forward_border<1, 2>(I, K, W + 1, L.perm);
+        } else if (K <= 128) {
+            inc_forward_border<2, 2>(I, K, W + 1, L.perm);
+        } else {
+            inc_forward_border<4, 2>(I, K, W + 1, L.perm);
+        }
         __syncthreads();
         PHASE(C, 5);
         // Schur block: H = AE V^-1 AE' (W x W, lower) into the scratch arena, t = AE V^-1 c into tv.
@@ -2067,8 +2105,27 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             pa = fmax(pa, fabs(p));
         }
     }
-    const double pinf = block_max(pa, L);  // its barriers also order the writes above
-    const int anyNan = block_or(pnan, L);
+    double pinf;
+    int anyNan;
+    {   // max |p| and "any NaN" in one exchange (its barriers also order the writes above)
+        const double wm = wave_max(pa);
+        const unsigned long long nb = __ballot(pnan);
+        if (lane == 0) {
+            L.red[wave] = wm;
+            L.ired[wave] = (nb != 0ull);
+        }
+        __syncthreads();
+        double r = L.red[0];
+        int f = L.ired[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            r = fmax(r, L.red[w]);
+            f |= L.ired[w];
+        }
+        __syncthreads();
+        pinf = r;
+        anyNan = f;
+    }
 
     // per-pass accounting (the R^2 terms only when gamma is formed)
     {
@@ -2129,8 +2186,8 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             if (k < K) {
                 const int i = L.idx[k];
                 const double t = L.zm[i], h = L.z[i];
-                if (t > tol && uhi[i] < inf) Lreg[m] = (uhi[i] - h) / t;
-                else if (t < -tol && dlo[i] > -inf) Lreg[m] = (dlo[i] - h) / t;
+                if (t > tol && ureg[m] < inf) Lreg[m] = (ureg[m] - h) / t;
+                else if (t < -tol && dreg[m] > -inf) Lreg[m] = (dreg[m] - h) / t;
                 if (Lreg[m] < ev.v) ev.v = Lreg[m];
             }
         }
@@ -2150,7 +2207,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
                     if (Lreg[m] < inf && !(Lreg[m] - L1 > tol)) {
                         const bool up = t > tol;
                         L.S[i] = up ? SSQP_UP : SSQP_DN;
-                        zn = up ? uhi[i] : dlo[i];
+                        zn = up ? ureg[m] : dreg[m];
                         firstId = min(firstId, i + 1);
                         if (zn != 0.0) L.ired[HB_DIRTY] = 1;  // B gains a column with a nonzero weight
                     }
