@@ -576,7 +576,7 @@ __device__ __forceinline__ int compact_free(const Lds &L, int N) {
             base += tot;
         }
     }
-    return base;
+    return uni(base);
 }
 
 __device__ __forceinline__ int compact_nonzero(const double *w, int N, bool dense, int16_t *list, const Lds &L) {
@@ -1074,17 +1074,22 @@ __device__ __forceinline__ double row_bcast(const double (&sl)[SL], int r) {
 template <int SL>
 __device__ __forceinline__ void inc_load_cols4(const Inc &I, int K, int c0, double (&l)[4][SL]) {
     const int lane = threadIdx.x & 63;
-    const int RC = I.RC;
+    const int RC = uni(I.RC);
+    K = uni(K);
+    c0 = uni(c0);
+    const int kl = (K > 0) ? K - 1 : 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int c = (c0 + u < K) ? c0 + u : (K > 0 ? K - 1 : 0);
+        const int c = (c0 + u < K) ? c0 + u : kl;  // scalar: column offsets stay on the scalar unit
         const int oc = cofs(c, RC) - c;
+        const int lim = (c0 + u < K) ? c : 0x7fffffff;
 #pragma unroll
         for (int t = 0; t < SL; ++t) {
             const int r = lane + 64 * t;
-            const bool below = (r > c && r < K && c0 + u < K);
-            const double v = I.fcol[oc + (below ? r : c)];
-            l[u][t] = below ? v : 0.0;
+            const int rk = (r < K) ? r : -1;
+            const int rm = (r < RC) ? r : RC - 1;
+            const double v = I.fcol[oc + (rm > c ? rm : c)];  // (always inside column c)
+            l[u][t] = (rk > lim) ? v : 0.0;
         }
     }
 }
@@ -1093,7 +1098,8 @@ __device__ __forceinline__ void inc_load_cols4(const Inc &I, int K, int c0, doub
 template <int SL>
 __device__ __forceinline__ bool inc_append(const Inc &I, int K, int j, const double *__restrict__ V, int N) {
     const int lane = threadIdx.x & 63;
-    const int RC = I.RC;
+    const int RC = uni(I.RC);
+    K = uni(K);
     const double *__restrict__ col = V + (size_t)j * N;
     const double vjj = col[j];
     double y[SL];
@@ -1144,7 +1150,9 @@ __device__ __forceinline__ bool inc_append(const Inc &I, int K, int j, const dou
 template <int SL>
 __device__ __forceinline__ void inc_delete_update(const Inc &I, int K, int p) {
     const int lane = threadIdx.x & 63;
-    const int RC = I.RC;
+    const int RC = uni(I.RC);
+    K = uni(K);
+    p = uni(p);
     const int op = cofs(p, RC) - p;
     double d[SL], w[SL];
 #pragma unroll
@@ -1193,7 +1201,9 @@ __device__ __forceinline__ void inc_delete_update(const Inc &I, int K, int p) {
 template <int SL>
 __device__ __forceinline__ void inc_delete_compact(const Inc &I, int K, int p) {
     const int lane = threadIdx.x & 63;
-    const int RC = I.RC;
+    const int RC = uni(I.RC);
+    K = uni(K);
+    p = uni(p);
     for (int c = 0; c < p; ++c) {  // (A) columns c < p lose row p: rows r > p move up by one inside the column
         const int oc = cofs(c, RC) - c;
         double a[SL];
@@ -1256,14 +1266,21 @@ __device__ __forceinline__ void inc_delete_compact(const Inc &I, int K, int p) {
 template <int SL, int NR>
 __device__ __forceinline__ void inc_forward_border(const Inc &I, int K, int nrhs, const int16_t *phys) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int RC = I.RC;
+    const int RC = uni(I.RC);
+    K = uni(K);
+    nrhs = uni(nrhs);
     for (int b0 = wave; b0 < nrhs; b0 += NR * NW) {
         double *Yp[NR];
         double y[NR][SL];
+        int ph[NR];
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
             const int b = b0 + NW * q;
-            Yp[q] = I.Y + (size_t)phys[b < nrhs ? b : b0] * RC;
+            ph[q] = phys[b < nrhs ? b : b0];
+        }
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            Yp[q] = I.Y + (size_t)uni(ph[q]) * RC;
 #pragma unroll
             for (int t = 0; t < SL; ++t) {
                 const int r = lane + 64 * t;
@@ -1311,7 +1328,8 @@ __device__ __forceinline__ void inc_forward_border(const Inc &I, int K, int nrhs
 template <int SL>
 __device__ __forceinline__ void inc_backward(const Inc &I, int K, double (&v)[SL]) {
     const int lane = threadIdx.x & 63;
-    const int RC = I.RC;
+    const int RC = uni(I.RC);
+    K = uni(K);
     int o[SL];
 #pragma unroll
     for (int t = 0; t < SL; ++t) {
@@ -1356,6 +1374,9 @@ template <int SL>
 __device__ __forceinline__ void inc_alpha(const Inc &I, int K, int W, int W0, const int16_t *phys, const double *aL,
                                           double *gam) {
     const int lane = threadIdx.x & 63;
+    K = uni(K);
+    W = uni(W);
+    W0 = uni(W0);
     const double *Yc = I.Y + (size_t)W0 * I.RC;
     double v[SL];
 #pragma unroll
@@ -1368,7 +1389,7 @@ __device__ __forceinline__ void inc_alpha(const Inc &I, int K, int W, int W0, co
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int w = (w0 + u < W) ? w0 + u : w0;
-            const double *Yw = I.Y + (size_t)phys[w] * I.RC;
+            const double *Yw = I.Y + (size_t)uni((int)phys[w]) * I.RC;
             aw[u] = aL[w];
 #pragma unroll
             for (int t = 0; t < SL; ++t) {
