@@ -208,6 +208,7 @@ struct Lds {
     int32_t *S;
     int *ired;                           // 2*NW + 8
     int16_t *pos, *idx, *perm, *rowsE, *ra, *iO, *fpos, *ordl;
+    int16_t *ytag;                       // row id behind each kept border column (16 entries)
 };
 
 __device__ __forceinline__ double block_max(double v, const Lds &L) {
@@ -1276,7 +1277,7 @@ __device__ __forceinline__ void inc_forward_border(const Inc &I, int K, int nrhs
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
             const int b = b0 + NW * q;
-            ph[q] = phys[b < nrhs ? b : b0];
+            ph[q] = phys ? (int)phys[b < nrhs ? b : b0] : (b < nrhs ? b : b0);
         }
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
@@ -1321,6 +1322,60 @@ __device__ __forceinline__ void inc_forward_border(const Inc &I, int K, int nrhs
                 }
             }
         }
+    }
+}
+
+// Rows r0..K-1 of the forward substitution for the border columns 0..nslot-1 of I.Y (their raw right-hand sides
+// already stored in those rows), given that rows < r0 are done: y_r = b_r - sum_{c<r} L(r,c) y_c, lanes over c.
+// After an append only the new last row is missing: one gathered row of L and one wavefront sum per column
+// instead of a sweep over the whole factor.  Columns over the wavefronts (k, k+NW, k+2NW by wavefront k).
+template <int SL>
+__device__ __forceinline__ void inc_forward_rows(const Inc &I, int K, int r0, int nslot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int RC = uni(I.RC);
+    K = uni(K);
+    r0 = uni(r0);
+    nslot = uni(nslot);
+    int o[SL];
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int c = lane + 64 * t;
+        o[t] = cofs(c < K ? c : 0, RC) - (c < K ? c : 0);
+    }
+    for (int r = r0; r < K; ++r) {
+        double lr[SL];
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int c = lane + 64 * t;
+            const double v = I.fcol[o[t] + (c < r ? r : (c < K ? c : 0))];  // L(r, c)
+            lr[t] = (c < r) ? v : 0.0;
+        }
+        for (int s0 = wave; s0 < nslot; s0 += 3 * NW) {
+            double part[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int sl = s0 + NW * q;
+                const double *Ys = I.Y + (size_t)(sl < nslot ? sl : s0) * RC;
+                double a = 0.0;
+#pragma unroll
+                for (int t = 0; t < SL; ++t) {
+                    const int c = lane + 64 * t;
+                    const double yv = Ys[c < K ? c : 0];
+                    a = fma(lr[t], (c < r) ? yv : 0.0, a);  // (rows >= r hold raw right-hand sides: masked)
+                }
+                part[q] = a;
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int sl = s0 + NW * q;
+                if (sl < nslot) {  // uniform per wavefront
+                    const double sum = wave_sum(part[q]);
+                    double *Ys = I.Y + (size_t)sl * RC;
+                    if (lane == 0) Ys[r] = Ys[r] - sum;
+                }
+            }
+        }
+        wave_sync();  // row r of this wavefront's columns feeds its row r+1
     }
 }
 
@@ -1432,10 +1487,12 @@ __device__ __forceinline__ void inc_alpha(const Inc &I, int K, int W, int W0, co
 // factor sync by ONE wavefront: delete the rows whose variable left F (highest row first), append the new free
 // variables by increasing index.  Returns the new row count, or -1 when an appended pivot is not > 0.
 __device__ __forceinline__ int inc_sync_w0(const Inc &I, int Kf, const Lds &L, const double *__restrict__ V, int N,
-                                           int K, int &nAppended) {
+                                           int K, int &nAppended, int &minDel) {
     const int lane = threadIdx.x & 63;
     nAppended = 0;
+    minDel = 0x7fffffff;  // lowest deleted row: the rows below it keep their forward-substituted border entries
     if (Kf < 0) {
+        minDel = 0;
         for (int i = lane; i < N; i += 64) L.fpos[i] = -1;
         Kf = 0;
         wave_sync();
@@ -1456,6 +1513,7 @@ __device__ __forceinline__ int inc_sync_w0(const Inc &I, int Kf, const Lds &L, c
                          inc_delete_compact<4>(I, Kf, pdel));
             SUBPHASE(17, tdel);
             PCOUNT(24);
+            minDel = pdel < minDel ? pdel : minDel;
             Kf -= 1;
         }
     }
@@ -1632,6 +1690,10 @@ struct ProbCtx {
     int RC;       // factor capacity (0: engine disabled for this problem shape)
     int yOff, rdvOff, facOff;  // offsets (doubles) of Y, 1/d and the factor in their arena
     int scrCap;                // doubles of scratch in front of them (LDS arena)
+    int fwdR0;                 // first row this pass still has to forward-substitute (front half)
+    bool fwdRows;              // ... row by row (few new rows) instead of a sweep over the factor
+    int yValid, yW0;           // leading rows of the border columns Y that are already forward-substituted for the
+                               // current factor, and the row count W0 they were formed for (front half)
     bool hbValid;              // L.hq holds hB + q of the current bound set (front half)
     bool facGlobal;            // engine state (factor, 1/d, Y) lives in the workgroup's GLOBAL arena (K grew past the LDS capacity)
 #ifdef SSQP_PHASE_PROFILE
@@ -1696,6 +1758,12 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         (long)2 * N + (long)W0 * (K + 1) + 8 <= C.scrCap) {
         PHASE(C, 1);
         const bool needHB = C.dense || !C.hbValid || (L.ired[HB_DIRTY] != 0);
+        // do the kept border columns Y still belong to the same constraint rows, slot by slot?
+        bool tagsSame = (W0 == C.yW0);
+        {
+            const bool bad = (lane < W0) && (L.rowsE[lane < W0 ? lane : 0] != L.ytag[lane < 16 ? lane : 0]);
+            if (__ballot(bad) != 0ull) tagsSame = false;
+        }
         double *X = ar + 2 * N;
         if (W0 > 0) {  // E-row sweep (SSQP.jl:290-295), rows over the wavefronts, every load of a wavefront's rows in flight
             // before the first use (W0 <= 12: at most three rows each)
@@ -1752,11 +1820,12 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         PHASE(C, 13);
         if (wave == 0) {
             SUBPHASE_DECL(tw0);
-            int nApp = 0;
-            const int Kf = inc_sync_w0(I, C.Kfac, L, V, N, K, nApp);
+            int nApp = 0, minDel = 0;
+            const int Kf = inc_sync_w0(I, C.Kfac, L, V, N, K, nApp, minDel);
             if (lane == 0) {
                 L.ired[2 * NW + 10] = Kf;
                 L.ired[2 * NW + 11] = nApp;
+                L.ired[2 * NW + 14] = minDel;
             }
             SUBPHASE(14, tw0);
         } else if (wave == 1) {
@@ -1801,15 +1870,34 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         // border right-hand sides AE' in factor order: from X in LDS when the register rank filter left it intact,
         // else (the LDS filter eliminated in place) gathered again from the constraint rows
         const bool xKept = !(W0 > 4 && K + 1 > 128);
-        for (int e = tid; e < W0 * K; e += NT) {
-            const int w = e / K, r = e - w * K;
-            const int iv = I.ord[r];
-            I.Y[(size_t)w * I.RC + r] = xKept ? X[w + W0 * (int)L.pos[iv]] : Ct[(size_t)L.rowsE[w] * N + iv];
+        // Forward substitution is causal (row r of L^-1 b needs rows <= r only): the entries of Y computed in the
+        // last pass stay valid for every row below the lowest deleted one, as long as the right-hand sides are
+        // the same (same constraint rows in the same slots, same hq).  After an append only the new row is missing.
+        int r0 = C.yValid;
+        {
+            const int minDel = uni(L.ired[2 * NW + 14]);
+            if (minDel < r0) r0 = minDel;
+            if (needHB || !tagsSame || r0 > K) r0 = 0;
         }
-        for (int r = tid; r < K; r += NT) {  // c = hB[F] + q[F]; hB = sum of the two partial vectors
-            const int i = I.ord[r];
-            I.Y[(size_t)W0 * I.RC + r] = needHB ? (ar[i] + ar[N + i]) + q[i] : L.hq[i];
+        const bool rowMode = (r0 > 0) && (K - r0 <= 2);
+        if (!rowMode) r0 = 0;
+        C.fwdR0 = r0;
+        C.fwdRows = rowMode;
+        {
+            const int nr = K - r0;  // raw right-hand sides of the rows still to be substituted
+            for (int e = tid; e < W0 * nr; e += NT) {
+                const int w = e / nr, r = r0 + (e - w * nr);
+                const int iv = I.ord[r];
+                I.Y[(size_t)w * I.RC + r] = xKept ? X[w + W0 * (int)L.pos[iv]] : Ct[(size_t)L.rowsE[w] * N + iv];
+            }
+            for (int r = r0 + tid; r < K; r += NT) {  // c = hB[F] + q[F]; hB = sum of the two partial vectors
+                const int i = I.ord[r];
+                I.Y[(size_t)W0 * I.RC + r] = needHB ? (ar[i] + ar[N + i]) + q[i] : L.hq[i];
+            }
         }
+        if (tid < W0 && tid < 16) L.ytag[tid] = L.rowsE[tid];
+        C.yW0 = W0;
+        C.yValid = K;
         if (needHB)
             for (int i = tid; i < N; i += NT) L.hq[i] = (ar[i] + ar[N + i]) + q[i];
         if (tid == 0) L.ired[HB_DIRTY] = 0;
@@ -1821,13 +1909,14 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     if (useInc && !frontDone) {
         PHASE(C, 13);
         if (wave == 0) {
-            int nApp = 0;
-            const int Kf = inc_sync_w0(I, C.Kfac, L, V, N, K, nApp);
+            int nApp = 0, minDel = 0;
+            const int Kf = inc_sync_w0(I, C.Kfac, L, V, N, K, nApp, minDel);
             if (lane == 0) {
                 L.ired[2 * NW + 10] = Kf;
                 L.ired[2 * NW + 11] = nApp;
             }
         }
+        C.yValid = 0;  // (this path refills and re-substitutes the border columns from scratch)
         __syncthreads();
         C.Kfac = uni(L.ired[2 * NW + 10]);
         C.sRead += 64ll * L.ired[2 * NW + 11] * K;  // the K scattered entries of each appended column
@@ -1933,13 +2022,22 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             __syncthreads();
         }
         PHASE(C, 4);
-        if (K <= 64) {
-            if (W + 1 > 2 * NW) inc_forward_border<1, 3>(I, K, W + 1, L.perm);
-            else inc_forward_border<1, 2>(I, K, W + 1, L.perm);
-        } else if (K <= 128) {
-            inc_forward_border<2, 2>(I, K, W + 1, L.perm);
+        if (frontDone && C.fwdRows) {  // only the rows appended since the last pass
+            if (C.fwdR0 < K)
+                INC_BY_SLOTS(K, inc_forward_rows<1>(I, K, C.fwdR0, W0 + 1), inc_forward_rows<2>(I, K, C.fwdR0, W0 + 1),
+                             inc_forward_rows<4>(I, K, C.fwdR0, W0 + 1));
         } else {
-            inc_forward_border<4, 2>(I, K, W + 1, L.perm);
+            // front half: every slot (all W0 rows and c), so that the columns stay valid for the next pass
+            const int16_t *phys = frontDone ? nullptr : L.perm;
+            const int nrhs = frontDone ? W0 + 1 : W + 1;
+            if (K <= 64) {
+                if (nrhs > 2 * NW) inc_forward_border<1, 3>(I, K, nrhs, phys);
+                else inc_forward_border<1, 2>(I, K, nrhs, phys);
+            } else if (K <= 128) {
+                inc_forward_border<2, 2>(I, K, nrhs, phys);
+            } else {
+                inc_forward_border<4, 2>(I, K, nrhs, phys);
+            }
         }
         __syncthreads();
         PHASE(C, 5);
@@ -2006,6 +2104,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         PHASE(C, 6);
     } else {
         C.Kfac = -1;  // the from-scratch path overwrites the arena: the kept factor is gone
+        C.yValid = 0;
     // ---- factor assembly: pass 1 over V[:,F] + border rows ----
     PHASE(C, 3);
     const int Rr = K + W + 1;
@@ -2451,6 +2550,8 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
     C.scrCap = P.arenaCap;
     C.facGlobal = false;
     C.hbValid = false;
+    C.yValid = 0;
+    C.yW0 = -1;
     if (tid == 0) L.ired[HB_DIRTY] = 0;
     if (P.incremental) {
         int rc = INC_KMAX;
@@ -2571,6 +2672,7 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
                 C.Kfac = 0;
             }
             C.facGlobal = true;
+            C.yValid = 0;  // (the border columns are not migrated)
             C.RC = RCg;
             C.yOff = (int)((long)NW * N + 64) + yOffG;
             C.rdvOff = (int)((long)NW * N + 64) + rdvOffG;
@@ -2654,6 +2756,7 @@ __global__ __launch_bounds__(NT, WPS) void ssqp_solve_kernel(SolveParams P) {
         L.iO = reinterpret_cast<int16_t *>(smem + lay.iO_bytes);
         L.fpos = reinterpret_cast<int16_t *>(smem + lay.fpos_bytes);
         L.ordl = reinterpret_cast<int16_t *>(smem + lay.ordl_bytes);
+        L.ytag = reinterpret_cast<int16_t *>(smem + lay.ytag_bytes);
     }
     double *garena = P.gscratch + (size_t)blockIdx.x * P.gscratchStride;
     for (;;) {
