@@ -148,6 +148,17 @@ __device__ __forceinline__ double wave_max(double v) {
     return bcast63_f64(v);
 }
 
+// maximum over lanes 0..15 only (a 16-lane DPP row: four steps, no cross-row traffic), as a uniform value
+__device__ __forceinline__ double row0_max(double v) {
+    v = fmax(v, dpp_f64<DPP_XOR1>(v));
+    v = fmax(v, dpp_f64<DPP_XOR2>(v));
+    v = fmax(v, dpp_f64<DPP_HALF_MIRROR>(v));
+    v = fmax(v, dpp_f64<DPP_MIRROR>(v));
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int srcLane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
@@ -187,16 +198,35 @@ __device__ __forceinline__ KeyMin keymin_rows(KeyMin a) {
     b.ord = __builtin_amdgcn_update_dpp(a.ord, a.ord, CTRL, ROWMASK, 0xF, false);
     return keymin(a, b);
 }
+__device__ __forceinline__ double wave_min(double v) {
+    v = fmin(v, dpp_f64<DPP_XOR1>(v));
+    v = fmin(v, dpp_f64<DPP_XOR2>(v));
+    v = fmin(v, dpp_f64<DPP_HALF_MIRROR>(v));
+    v = fmin(v, dpp_f64<DPP_MIRROR>(v));
+    v = fmin(v, dpp_f64_rows<0x142, 0xA>(v, v));
+    v = fmin(v, dpp_f64_rows<0x143, 0xC>(v, v));
+    return bcast63_f64(v);
+}
+// Two steps instead of a (value, order) pair through every reduction stage: the minimum value first, then the
+// smallest order among the lanes that hold it (one lane unless values tie exactly).  Values must not be NaN.
 __device__ __forceinline__ KeyMin wave_keymin(KeyMin a) {
-    a = keymin_dpp<DPP_XOR1>(a);
-    a = keymin_dpp<DPP_XOR2>(a);
-    a = keymin_dpp<DPP_HALF_MIRROR>(a);
-    a = keymin_dpp<DPP_MIRROR>(a);
-    a = keymin_rows<0x142, 0xA>(a);
-    a = keymin_rows<0x143, 0xC>(a);
     KeyMin r;
-    r.v = bcast63_f64(a.v);
-    r.ord = __builtin_amdgcn_readlane(a.ord, 63);
+    r.v = wave_min(a.v);
+    const bool mine = (a.v == r.v);
+    unsigned long long tie = __ballot(mine);
+    int o = __builtin_amdgcn_readlane(a.ord, __ffsll((long long)tie) - 1);
+    tie &= tie - 1;
+    if (tie) {  // exact ties (or a wavefront without any candidate, all at +inf): integer minimum over the tied lanes
+        int q = mine ? a.ord : 0x7fffffff;
+        q = min(q, dpp_i32<DPP_XOR1>(q));
+        q = min(q, dpp_i32<DPP_XOR2>(q));
+        q = min(q, dpp_i32<DPP_HALF_MIRROR>(q));
+        q = min(q, dpp_i32<DPP_MIRROR>(q));
+        q = min(q, __builtin_amdgcn_update_dpp(q, q, 0x142, 0xA, 0xF, false));
+        q = min(q, __builtin_amdgcn_update_dpp(q, q, 0x143, 0xC, 0xF, false));
+        o = __builtin_amdgcn_readlane(q, 63);
+    }
+    r.ord = o;
     return r;
 }
 
@@ -219,6 +249,17 @@ __device__ __forceinline__ double block_max(double v, const Lds &L) {
     double r = L.red[0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) r = fmax(r, L.red[w]);
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ double block_min(double v, const Lds &L) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_min(v);
+    if (lane == 0) L.red[wave] = v;
+    __syncthreads();
+    double r = L.red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) r = fmin(r, L.red[w]);
     __syncthreads();
     return r;
 }
@@ -784,7 +825,7 @@ __device__ __forceinline__ int rank_filter_regs(const double *X, int W0, int nc,
             am = better ? a : am;
             ap = better ? posn[cs] : ap;
         }
-        const double m = wave_max(am);
+        const double m = (CS == 1 && nc <= 16) ? row0_max(am) : wave_max(am);  // (lanes >= nc hold -1)
         if (m > tol) {  // utils.jl:61 (uniform)
             // first maximum in c0 order: the tied lane with the smallest position (one lane but for exact ties)
             unsigned long long tie = __ballot(am == m);
@@ -1439,13 +1480,16 @@ __device__ __forceinline__ void inc_alpha(const Inc &I, int K, int W, int W0, co
         const int r = lane + 64 * t;
         v[t] = (r < K) ? Yc[r] : 0.0;
     }
+    // lane w fetches the slot and the weight of border column w once; they are handed out by v_readlane below
+    const int physv = phys[lane < W ? lane : 0];
+    const double aLv = aL[lane < W ? lane : 0];
     for (int w0 = 0; w0 < W; w0 += 4) {  // four border columns per trip, their loads issued together
         double yw[4][SL], aw[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int w = (w0 + u < W) ? w0 + u : w0;
-            const double *Yw = I.Y + (size_t)uni((int)phys[w]) * I.RC;
-            aw[u] = aL[w];
+            const double *Yw = I.Y + (size_t)__builtin_amdgcn_readlane(physv, w) * I.RC;
+            aw[u] = readlane_f64(aLv, w);
 #pragma unroll
             for (int t = 0; t < SL; ++t) {
                 const int r = lane + 64 * t;
@@ -1641,9 +1685,9 @@ __device__ __forceinline__ bool small_spd_solve(const double *H, const double *r
             y = below ? fma(-lic, yc, y) : ((lane == c) ? y * r : y);  // forward substitution rides along; D^-1 on row c
 #pragma unroll
             for (int c2 = 0; c2 < WM; ++c2) {  // (columns beyond W hold zeros: no guard on W)
-                if (c2 > c) {
+                if (c2 > c) {  // (rows <= c are finished and never read again: no predicate)
                     const double bq = readlane_f64(a[c], c2);
-                    a[c2] = below ? fma(-lic, bq, a[c2]) : a[c2];
+                    a[c2] = fma(-lic, bq, a[c2]);
                 }
             }
             if (below && lane < WM) tr[c * WM + lane] = lic;
@@ -1834,6 +1878,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             if (W0 > 0) {
                 if (W0 <= 4 && K + 1 <= 128) w = rank_filter_regs<4, 2>(X, W0, K + 1, tol, L);
                 else if (W0 <= 4) w = rank_filter_regs<4, 4>(X, W0, K + 1, tol, L);
+                else if (K + 1 <= 64 && W0 <= 8) w = rank_filter_regs<8, 1>(X, W0, K + 1, tol, L);
                 else if (K + 1 <= 64) w = rank_filter_regs<RF_ROWS, 1>(X, W0, K + 1, tol, L);
                 else if (K + 1 <= 128) w = rank_filter_regs<RF_ROWS, 2>(X, W0, K + 1, tol, L);
                 else w = rank_filter_wave(X, W0, K + 1, tol, L);
@@ -2313,7 +2358,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         }
         for (int o = tid; o < JO; o += NT)
             if (L.lin[o] < ev.v) ev.v = L.lin[o];
-        const double L1 = block_keymin(ev, L).v;
+        const double L1 = block_min(ev.v, L);
         C.sFlops += 2ll * JO * (N + K);
         if (L1 < 1.0) {  // blocked  (:98-127)
             int firstId = 0x7fffffff;
