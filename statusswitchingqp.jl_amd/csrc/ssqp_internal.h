@@ -47,7 +47,7 @@ struct SolveParams {
 // Offsets of the LDS carve-up.  Double-typed regions first (offsets in
 // doubles), then the integer regions (offsets in bytes).
 struct LdsLayout {
-    int z, zm, gam, hq, arena, bE, aL, tv, dcol, lin, red;  // in doubles
+    int z, zm, gam, hq, arena, bE, aL, tv, dcol, lin, bEall, red;  // in doubles
     int S_bytes, ired_bytes, pos_bytes, idx_bytes, perm_bytes, rowsE_bytes, ra_bytes, iO_bytes, fpos_bytes, ordl_bytes, ytag_bytes;
     int total_bytes;
 };
@@ -57,7 +57,7 @@ __host__ __device__ inline int align_up(int x, int a) { return (x + a - 1) / a *
 // bytes of everything except the arena
 __host__ __device__ inline int lds_fixed_bytes(int N, int M, int J) {
     const int MJ1 = align_up(M + J + 1, 2);
-    int dbl = 4 * align_up(N, 2) + 5 * MJ1 + 2 * NW;  // z, zm, gam, hq | bE, aL, tv, dcol, lin | red
+    int dbl = 4 * align_up(N, 2) + 6 * MJ1 + 2 * NW;  // z, zm, gam, hq | bE, aL, tv, dcol, lin, bEall | red
     int bytes = dbl * 8;
     bytes += align_up(4 * (N + J), 8);           // S
     bytes += align_up(4 * (2 * NW + 16 + NW * MAXPT), 8);  // ired (+ per-chunk wave counts of the compaction)
@@ -81,6 +81,7 @@ __host__ __device__ inline LdsLayout lds_layout(int N, int M, int J, int arenaCa
     l.tv = o; o += MJ1;
     l.dcol = o; o += MJ1;
     l.lin = o; o += MJ1;
+    l.bEall = o; o += MJ1;
     l.red = o; o += 2 * NW;
     l.arena = o; o += align_up(arenaCap, 2);
     int b = o * 8;

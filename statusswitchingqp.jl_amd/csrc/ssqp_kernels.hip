@@ -101,14 +101,28 @@ __device__ unsigned long long g_phase[1024 * 32];
 // cross-row steps use the 64-lane shuffle.  Every lane ends with the result.  All 64 lanes must be active.
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
+    // (every lane is written by these in-row permutes: no `old` operand, so no copy in front of the v_mov_dpp)
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) {
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, false);
+}
+// v_max_f64 / v_min_f64 as single instructions: fmax()/fmin() put a canonicalising v_max(x, x) in front of every
+// operand (signalling-NaN semantics), which doubles the length of the reduction chains.  Operands here are
+// never NaN by construction (|x|, ratios already filtered, +-inf sentinels).
+__device__ __forceinline__ double max_raw(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double min_raw(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
 constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
@@ -139,21 +153,21 @@ __device__ __forceinline__ double wave_sum(double v) {
     return bcast63_f64(v);
 }
 __device__ __forceinline__ double wave_max(double v) {
-    v = fmax(v, dpp_f64<DPP_XOR1>(v));
-    v = fmax(v, dpp_f64<DPP_XOR2>(v));
-    v = fmax(v, dpp_f64<DPP_HALF_MIRROR>(v));
-    v = fmax(v, dpp_f64<DPP_MIRROR>(v));
-    v = fmax(v, dpp_f64_rows<0x142, 0xA>(v, v));
-    v = fmax(v, dpp_f64_rows<0x143, 0xC>(v, v));
+    v = max_raw(v, dpp_f64<DPP_XOR1>(v));
+    v = max_raw(v, dpp_f64<DPP_XOR2>(v));
+    v = max_raw(v, dpp_f64<DPP_HALF_MIRROR>(v));
+    v = max_raw(v, dpp_f64<DPP_MIRROR>(v));
+    v = max_raw(v, dpp_f64_rows<0x142, 0xA>(v, v));
+    v = max_raw(v, dpp_f64_rows<0x143, 0xC>(v, v));
     return bcast63_f64(v);
 }
 
 // maximum over lanes 0..15 only (a 16-lane DPP row: four steps, no cross-row traffic), as a uniform value
 __device__ __forceinline__ double row0_max(double v) {
-    v = fmax(v, dpp_f64<DPP_XOR1>(v));
-    v = fmax(v, dpp_f64<DPP_XOR2>(v));
-    v = fmax(v, dpp_f64<DPP_HALF_MIRROR>(v));
-    v = fmax(v, dpp_f64<DPP_MIRROR>(v));
+    v = max_raw(v, dpp_f64<DPP_XOR1>(v));
+    v = max_raw(v, dpp_f64<DPP_XOR2>(v));
+    v = max_raw(v, dpp_f64<DPP_HALF_MIRROR>(v));
+    v = max_raw(v, dpp_f64<DPP_MIRROR>(v));
     const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
     const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
     return __hiloint2double(hi, lo);
@@ -199,12 +213,12 @@ __device__ __forceinline__ KeyMin keymin_rows(KeyMin a) {
     return keymin(a, b);
 }
 __device__ __forceinline__ double wave_min(double v) {
-    v = fmin(v, dpp_f64<DPP_XOR1>(v));
-    v = fmin(v, dpp_f64<DPP_XOR2>(v));
-    v = fmin(v, dpp_f64<DPP_HALF_MIRROR>(v));
-    v = fmin(v, dpp_f64<DPP_MIRROR>(v));
-    v = fmin(v, dpp_f64_rows<0x142, 0xA>(v, v));
-    v = fmin(v, dpp_f64_rows<0x143, 0xC>(v, v));
+    v = min_raw(v, dpp_f64<DPP_XOR1>(v));
+    v = min_raw(v, dpp_f64<DPP_XOR2>(v));
+    v = min_raw(v, dpp_f64<DPP_HALF_MIRROR>(v));
+    v = min_raw(v, dpp_f64<DPP_MIRROR>(v));
+    v = min_raw(v, dpp_f64_rows<0x142, 0xA>(v, v));
+    v = min_raw(v, dpp_f64_rows<0x143, 0xC>(v, v));
     return bcast63_f64(v);
 }
 // Two steps instead of a (value, order) pair through every reduction stage: the minimum value first, then the
@@ -234,6 +248,7 @@ struct Lds {
     double *z, *zm, *gam, *arena;
     double *hq;                          // cached hB + q (see the front half of iterate_kkt)
     double *bE, *aL, *tv, *dcol, *lin;  // MJ+1 each
+    double *bEall;                       // b - [A;G] zB for EVERY row, valid together with hq (front half)
     double *red;                         // 2*NW
     int32_t *S;
     int *ired;                           // 2*NW + 8
@@ -1809,6 +1824,44 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             if (__ballot(bad) != 0ull) tagsSame = false;
         }
         double *X = ar + 2 * N;
+        // E rows (SSQP.jl:290-295).  bE = b - [A;G] zB only changes with zB, like hB: when every row fits the batch
+        // (MJ <= 12) it is kept for ALL rows next to hq and re-evaluated only on needHB; the entries X needs,
+        // AE = [A;G][E, F], are then a K x W0 gather (one element per thread) instead of full-row sweeps.
+        const bool cacheBE = (MJ <= RF_ROWS);
+        if (cacheBE) {
+            if (needHB && MJ > 0) {
+                constexpr int RPW = (RF_ROWS + NW - 1) / NW;
+                const double *__restrict__ rows[RPW];
+                double rh[RPW];
+#pragma unroll
+                for (int t = 0; t < RPW; ++t) {
+                    const int rid = wave + NW * t;
+                    const int rc = rid < MJ ? rid : 0;
+                    rows[t] = (rid < MJ || t == 0) ? Ct + (size_t)rc * N : nullptr;
+                    rh[t] = rhs[rc];
+                }
+                double a1[RPW], a2[RPW];
+                rows_dot2_batch<RPW>(rows, L.zm, L.zm, N, lane, a1, a2);
+#pragma unroll
+                for (int t = 0; t < RPW; ++t) {
+                    const int rid = wave + NW * t;
+                    if (rid < MJ) {  // uniform per wavefront
+                        const double acc = wave_sum(a1[t]);
+                        if (lane == 0) L.bEall[rid] = rh[t] - acc;
+                    }
+                }
+            }
+            for (int e = tid; e < W0 * K; e += NT) {
+                const int k = e / W0, w = e - k * W0;
+                X[e] = Ct[(size_t)L.rowsE[w] * N + L.idx[k]];  // X[w + W0*k]
+            }
+            if (needHB) __syncthreads();  // (bEall of this pass)
+            if (tid < W0) {
+                const double be = L.bEall[L.rowsE[tid]];
+                L.bE[tid] = be;
+                X[tid + W0 * K] = be;
+            }
+        } else
         if (W0 > 0) {  // E-row sweep (SSQP.jl:290-295), rows over the wavefronts, every load of a wavefront's rows in flight
             // before the first use (W0 <= 12: at most three rows each)
             constexpr int RPW = (RF_ROWS + NW - 1) / NW;
@@ -2790,6 +2843,7 @@ __global__ __launch_bounds__(NT, WPS) void ssqp_solve_kernel(SolveParams P) {
         L.tv = d0 + lay.tv;
         L.dcol = d0 + lay.dcol;
         L.lin = d0 + lay.lin;
+        L.bEall = d0 + lay.bEall;
         L.red = d0 + lay.red;
         L.S = reinterpret_cast<int32_t *>(smem + lay.S_bytes);
         L.ired = reinterpret_cast<int *>(smem + lay.ired_bytes);
