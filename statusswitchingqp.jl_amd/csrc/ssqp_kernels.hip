@@ -196,7 +196,8 @@ struct KeyMin {  // minimum value, ties -> smallest order
     int ord;
 };
 __device__ __forceinline__ KeyMin keymin(KeyMin a, KeyMin b) {
-    return (b.v < a.v || (b.v == a.v && b.ord < a.ord)) ? b : a;
+    const bool take = (b.v < a.v) | ((b.v == a.v) & (b.ord < a.ord));  // (no short circuit: straight-line code)
+    return KeyMin{take ? b.v : a.v, take ? b.ord : a.ord};
 }
 template <int CTRL>
 __device__ __forceinline__ KeyMin keymin_dpp(KeyMin a) {
@@ -834,9 +835,9 @@ __device__ __forceinline__ int rank_filter_regs(const double *X, int W0, int nc,
         int ap = 0x7fffffff;
 #pragma unroll
         for (int cs = 0; cs < CS; ++cs) {
-            const bool in = posn[cs] >= j && posn[cs] < nc;
+            const bool in = (posn[cs] >= j) & (posn[cs] < nc);
             const double a = in ? fabs(x[cs][0]) : -1.0;
-            const bool better = (a > am) || (a == am && posn[cs] < ap);
+            const bool better = (a > am) | ((a == am) & (posn[cs] < ap));  // (no short circuit: straight-line code)
             am = better ? a : am;
             ap = better ? posn[cs] : ap;
         }
