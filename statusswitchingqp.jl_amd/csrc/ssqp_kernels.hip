@@ -841,14 +841,17 @@ __device__ __forceinline__ int rank_filter_regs(const double *X, int W0, int nc,
             am = better ? a : am;
             ap = better ? posn[cs] : ap;
         }
-        const double m = (CS == 1 && nc <= 16) ? row0_max(am) : wave_max(am);  // (lanes >= nc hold -1)
+        const double m = wave_max(am);  // (lanes >= nc hold -1)
         if (m > tol) {  // utils.jl:61 (uniform)
             // first maximum in c0 order: the tied lane with the smallest position (one lane but for exact ties)
             unsigned long long tie = __ballot(am == m);
-            int mpos = __builtin_amdgcn_readlane(ap, __ffsll((long long)tie) - 1);
+            int mlane = __ffsll((long long)tie) - 1;
+            int mpos = __builtin_amdgcn_readlane(ap, mlane);
             tie &= tie - 1;
             while (tie) {
-                const int p2 = __builtin_amdgcn_readlane(ap, __ffsll((long long)tie) - 1);
+                const int l2 = __ffsll((long long)tie) - 1;
+                const int p2 = __builtin_amdgcn_readlane(ap, l2);
+                mlane = p2 < mpos ? l2 : mlane;
                 mpos = p2 < mpos ? p2 : mpos;
                 tie &= tie - 1;
             }
@@ -856,6 +859,12 @@ __device__ __forceinline__ int rank_filter_regs(const double *X, int W0, int nc,
             nrows += 1;
             // c0[mj] <-> c0[j]; then the pivot column (now at position j) broadcasts its entries of this row and below
             double dcol[ROWS];
+            if (CS == 1) {  // one column per lane: the pivot column is the winning lane's
+                const int pz = posn[0];
+                posn[0] = (pz == mpos) ? j : ((pz == j) ? mpos : pz);
+#pragma unroll
+                for (int k = 0; k < ROWS; ++k) dcol[k] = readlane_f64(x[0][k], mlane);
+            } else {
 #pragma unroll
             for (int k = 0; k < ROWS; ++k) dcol[k] = 0.0;
 #pragma unroll
@@ -868,6 +877,7 @@ __device__ __forceinline__ int rank_filter_regs(const double *X, int W0, int nc,
 #pragma unroll
                     for (int k = 0; k < ROWS; ++k) dcol[k] = readlane_f64(x[cs][k], src);
                 }
+            }
             }
 #pragma unroll
             for (int cs = 0; cs < CS; ++cs) {
@@ -1852,9 +1862,11 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
                     }
                 }
             }
-            for (int e = tid; e < W0 * K; e += NT) {
-                const int k = e / W0, w = e - k * W0;
-                X[e] = Ct[(size_t)L.rowsE[w] * N + L.idx[k]];  // X[w + W0*k]
+            {   // (16 slots x 16 columns per trip: no integer division)
+                const int w = tid & 15;
+                const int rid = L.rowsE[w < W0 ? w : 0];
+                for (int k = tid >> 4; k < K; k += NT / 16)
+                    if (w < W0) X[w + W0 * k] = Ct[(size_t)rid * N + L.idx[k]];
             }
             if (needHB) __syncthreads();  // (bEall of this pass)
             if (tid < W0) {
