@@ -1760,6 +1760,7 @@ struct ProbCtx {
     int RC;       // factor capacity (0: engine disabled for this problem shape)
     int yOff, rdvOff, facOff;  // offsets (doubles) of Y, 1/d and the factor in their arena
     int scrCap;                // doubles of scratch in front of them (LDS arena)
+    double qr0, qr1;           // this thread's two entries of q, requested early for the refresh of hq (per thread)
     int fwdR0;                 // first row this pass still has to forward-substitute (front half)
     bool fwdRows;              // ... row by row (few new rows) instead of a sweep over the factor
     int yValid, yW0;           // leading rows of the border columns Y that are already forward-substituted for the
@@ -1840,6 +1841,20 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         // AE = [A;G][E, F], are then a K x W0 gather (one element per thread) instead of full-row sweeps.
         const bool cacheBE = (MJ <= RF_ROWS);
         if (cacheBE) {
+            // AE entries for X: one 8-byte gather per thread and trip (16 slots x 16 columns, no integer division);
+            // the first trip's load is issued before the row sweep below, so both wait on memory together
+            const int wX = tid & 15;
+            const int ridX = L.rowsE[wX < W0 ? wX : 0];
+            const int kX = tid >> 4;
+            double x0v = 0.0;
+            if (wX < W0 && kX < K) x0v = Ct[(size_t)ridX * N + L.idx[kX]];
+            // q for the refresh of hq after the join (needed ~10 k cycles from now)
+            double qreg[MPT];
+#pragma unroll
+            for (int m = 0; m < MPT; ++m) {
+                const int i = tid + m * NT;
+                qreg[m] = (needHB && i < N) ? q[i] : 0.0;
+            }
             if (needHB && MJ > 0) {
                 constexpr int RPW = (RF_ROWS + NW - 1) / NW;
                 const double *__restrict__ rows[RPW];
@@ -1862,12 +1877,11 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
                     }
                 }
             }
-            {   // (16 slots x 16 columns per trip: no integer division)
-                const int w = tid & 15;
-                const int rid = L.rowsE[w < W0 ? w : 0];
-                for (int k = tid >> 4; k < K; k += NT / 16)
-                    if (w < W0) X[w + W0 * k] = Ct[(size_t)rid * N + L.idx[k]];
-            }
+            if (wX < W0 && kX < K) X[wX + W0 * kX] = x0v;
+            for (int k = kX + NT / 16; k < K; k += NT / 16)
+                if (wX < W0) X[wX + W0 * k] = Ct[(size_t)ridX * N + L.idx[k]];
+            C.qr0 = qreg[0];
+            C.qr1 = (MPT > 1) ? qreg[MPT > 1 ? 1 : 0] : 0.0;
             if (needHB) __syncthreads();  // (bEall of this pass)
             if (tid < W0) {
                 const double be = L.bEall[L.rowsE[tid]];
@@ -2009,8 +2023,14 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         if (tid < W0 && tid < 16) L.ytag[tid] = L.rowsE[tid];
         C.yW0 = W0;
         C.yValid = K;
-        if (needHB)
-            for (int i = tid; i < N; i += NT) L.hq[i] = (ar[i] + ar[N + i]) + q[i];
+        if (needHB) {
+            if (MJ <= RF_ROWS) {  // (q was requested before the E pass: see cacheBE)
+                if (tid < N) L.hq[tid] = (ar[tid] + ar[N + tid]) + C.qr0;
+                if (tid + NT < N) L.hq[tid + NT] = (ar[tid + NT] + ar[N + tid + NT]) + C.qr1;
+            } else {
+                for (int i = tid; i < N; i += NT) L.hq[i] = (ar[i] + ar[N + i]) + q[i];
+            }
+        }
         if (tid == 0) L.ired[HB_DIRTY] = 0;
         C.hbValid = true;
         if (tid <= Wspec) L.perm[tid] = (tid < Wspec) ? L.ra[tid] : (int16_t)W0;  // physical right-hand sides
@@ -2546,6 +2566,13 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             }
             __syncthreads();
         }
+        if (W == W0) {  // every active row kept its own multiplier: one thread per row
+            if (tid < JE) {
+                const int wrow = M + tid;
+                const double Lda = L.aL[wrow];
+                if (Lda < -tolG) ev = keymin(ev, KeyMin{Lda, N + (int)L.rowsE[wrow] - M});
+            }
+        } else
         for (int e = 0; e < JE; ++e) {  // JE is small; uniform loop
             const int wrow = M + e;       // index into rowsE
             int posk = -1;
