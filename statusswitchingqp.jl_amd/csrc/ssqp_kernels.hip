@@ -2133,6 +2133,18 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         __syncthreads();
     }
 
+    // ratio-test rows fetched ahead by the wavefronts that idle during the lambda / alpha solve (see below)
+    constexpr int PRE = 2;       // rows per prefetching wavefront (wavefronts 1..3: up to 6 inactive rows)
+    double2 gpre[PRE][4];
+    double azpre[PRE], rhpre[PRE];
+    int npre = 0;
+#pragma unroll
+    for (int t = 0; t < PRE; ++t) {
+        azpre[t] = 0.0;
+        rhpre[t] = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) gpre[t][m] = make_double2(0.0, 0.0);
+    }
     double *fac = ar;  // (from-scratch path: packed factor; least-squares scratch of KKTchk! in both paths)
     if (useInc) {
         // =========================== incremental engine ===========================
@@ -2225,7 +2237,41 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
                 INC_BY_SLOTS(K, inc_alpha<1>(I, K, W, W0, L.perm, L.aL, L.gam),
                              inc_alpha<2>(I, K, W, W0, L.perm, L.aL, L.gam),
                              inc_alpha<4>(I, K, W, W0, L.perm, L.aL, L.gam));
+        } else if (VEC == 2) {
+            // meanwhile the other wavefronts fetch the rows of the inactive inequalities for aStep! (G z is formed
+            // now, G p once p exists): the memory round trip of the ratio test is off the critical path
+            npre = (JO < 3 * PRE) ? JO : 3 * PRE;
+#pragma unroll
+            for (int t = 0; t < PRE; ++t) {
+                const int o = (wave - 1) + 3 * t;
+                if (o < npre) {  // uniform per wavefront
+                    const int j = L.iO[o];
+                    const double *__restrict__ row = Ct + (size_t)(M + j) * N;
+                    rhpre[t] = rhs[M + j];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int r = lane * 2 + 128 * m;
+                        gpre[t][m] = *reinterpret_cast<const double2 *>(row + (r < N ? r : 0));
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < PRE; ++t) {
+                const int o = (wave - 1) + 3 * t;
+                if (o < npre) {
+                    double s1 = 0.0;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int r = lane * 2 + 128 * m;
+                        const double2 zz = *reinterpret_cast<const double2 *>(L.z + (r < N ? r : 0));
+                        const double n1 = fma(gpre[t][m].y, zz.y, fma(gpre[t][m].x, zz.x, s1));
+                        s1 = (r < N) ? n1 : s1;
+                    }
+                    azpre[t] = s1;
+                }
+            }
         }
+        if (VEC == 2) npre = (JO < 3 * PRE) ? JO : 3 * PRE;
         __syncthreads();
         if (!L.ired[2 * NW + 2]) {
             C.ret = -1;
@@ -2392,8 +2438,26 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         // inactive inequalities: zo = g - G z, po = G[:,F] p   (:78-89)
         SUBPHASE_DECL(tast);
         if (VEC == 2) {
+            if (wave > 0) {  // rows fetched during the lambda / alpha solve
+#pragma unroll
+                for (int t = 0; t < PRE; ++t) {
+                    const int o = (wave - 1) + 3 * t;
+                    if (o < npre) {  // uniform per wavefront
+                        double s2 = 0.0;
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            const int r = lane * 2 + 128 * m;
+                            const double2 pp = *reinterpret_cast<const double2 *>(L.zm + (r < N ? r : 0));
+                            const double n2 = fma(gpre[t][m].y, pp.y, fma(gpre[t][m].x, pp.x, s2));
+                            s2 = (r < N) ? n2 : s2;
+                        }
+                        const double sz = wave_sum(azpre[t]), sp = wave_sum(s2);
+                        if (lane == 0) L.lin[o] = (sp > tol) ? (rhpre[t] - sz) / sp : inf;
+                    }
+                }
+            }
             constexpr int RPW = 3;  // rows per wavefront and batch
-            for (int o0 = 0; o0 < JO; o0 += NW * RPW) {
+            for (int o0 = npre; o0 < JO; o0 += NW * RPW) {
                 const double *__restrict__ rows[RPW];
                 double rh[RPW];
 #pragma unroll
