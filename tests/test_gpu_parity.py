@@ -233,11 +233,25 @@ def test_random_shapes_and_bounds(pkg, orc, kind):
     import zlib
     rng = np.random.default_rng(zlib.crc32(kind.encode()))
     shapes = [(24, 1, 0), (40, 1, 3), (57, 2, 4), (64, 1, 6), (96, 3, 8), (130, 1, 10), (150, 2, 5), (200, 1, 2)]
+    _check_shapes(pkg, orc, kind, rng, shapes, 12, 40)
+
+
+@pytest.mark.parametrize("kind", ["plain", "lower_bounds", "dup_rows"])
+def test_many_inequalities_and_wide_shapes(pkg, orc, kind):
+    """more constraint rows than the cached-row batch holds (M+J > 12: full row sweeps, possibly more than 12 active
+    rows -> the workgroup rank filter and the from-scratch factorisation), and N up to 512 with up to 12 rows"""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(("wide" + kind).encode()))
+    shapes = [(80, 1, 14), (120, 2, 20), (96, 1, 12), (256, 1, 11), (384, 2, 9), (512, 1, 6)]
+    _check_shapes(pkg, orc, kind, rng, shapes, 6, 20)
+
+
+def _check_shapes(pkg, orc, kind, rng, shapes, nper, need):
     total = 0
     for (N, M, J) in shapes:
         ub = rng.uniform(2.0, 6.0) / N if kind != "some_free" else 0.0
         cfg = pkg.GenConfig(N, M, J, 2 * N, 1e-3, ub, rng.uniform(0.93, 1.1), rng.uniform(0.0, 0.3))
-        prob = pkg.generate_batch(cfg, 12, int(rng.integers(1, 2 ** 31)))
+        prob = pkg.generate_batch(cfg, nper, int(rng.integers(1, 2 ** 31)))
         prob = _mutate(prob, rng, kind)
         x0, S0, st = pkg.phase1_batch(prob)
         ok = st == 1
@@ -253,7 +267,7 @@ def test_random_shapes_and_bounds(pkg, orc, kind):
         scale = np.maximum(np.abs(zo[fin]).max(axis=1), 1e-300)
         assert (np.abs(z[fin] - zo[fin]).max(axis=1) / scale).max() < 1e-10 if fin.any() else True
         total += int(conv.sum())
-    assert total > 40
+    assert total > need
 
 
 def test_shared_v_batch_efficient_frontier_style(pkg, orc):
