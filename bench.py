@@ -9,6 +9,11 @@ synthetic QPs already resident in HBM: BASELINE.json configs[3] ("8192 independe
 sharded across 8 GPUs") = 1024 QPs per GPU, cfg2-style problems (M=1, J=10, box bounds).
 Weak scaling: every rank owns 1024 problems; the only collective is the final RCCL all-gather of
 (z, S, status), inside the timed region.  Rank 0 prints ONE JSON line.
+
+Consecutive steps are independent batches; they are issued round-robin on `--streams` HIP streams (default 3, one
+library context per lane), so the drain of one launch -- persistent workgroups run dry at different times -- overlaps
+the start of the next.  `--streams 1` gives serial launches; the JSON carries both figures (`pipeline`), and the
+roofline figures always come from single launches timed by their own HIP events.
 """
 import argparse
 import json
@@ -33,6 +38,8 @@ def main():
     ap.add_argument("--config", default="cfg4", help="problem family (statusswitchingqp.jl_amd CONFIGS)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="launch lanes: consecutive steps go round-robin to this many HIP streams (1: serial launches)")
     ap.add_argument("--skip-dense", action="store_true",
                     help="do not time the dense-formulation launches (profiling runs want one kernel variant)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"),
@@ -75,20 +82,34 @@ def main():
     t_setup = time.time() - t0
     P, N, J = batch.P, batch.N, batch.J
     stream = torch.cuda.current_stream(dev)
+    # Launch lanes: consecutive steps are independent batches, so they are issued round-robin on `--streams` HIP
+    # streams (one context = workspace + work counter per lane, inputs shared, outputs per lane).  Inside one
+    # launch the persistent workgroups run dry at different times (143..262 passes per QP, two QPs per slot):
+    # with a single stream ~20 % of the slot-time of every launch is that drain; with a few lanes the next
+    # launch's workgroups take the freed slots.  Every step still solves all its QPs from (x0, S0).
+    nlanes = max(1, args.streams)
+    lanes = [(batch, stream)]
+    for _ in range(1, nlanes):
+        lanes.append((batch.twin(pkg.Context(local)), torch.cuda.Stream(dev)))
+    step_no = [0]
 
     def step():
-        batch.solve()                       # in-kernel active-set loop, asynchronous on torch's stream
-        if world > 1:                       # final gather of the sharded batch (RCCL over xGMI)
-            pkg.dist.gather_results(batch.z, batch.S, batch.status)
+        b, st = lanes[step_no[0] % nlanes]
+        step_no[0] += 1
+        with torch.cuda.stream(st):
+            b.solve()                       # in-kernel active-set loop, asynchronous on the lane's stream
+            if world > 1:                   # final gather of the sharded batch (RCCL over xGMI)
+                pkg.dist.gather_results(b.z, b.S, b.status)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, nlanes)):   # (every lane is warmed once)
         step()
     fence()
+    step_no[0] = 0
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -102,7 +123,12 @@ def main():
         elapsed = float(tt.item())
 
     res = batch.results()
-    ok = bool((res["status"] > 0).all())
+    lanes_agree = True
+    for lb, _ in lanes[1:]:                 # every lane solved the same batch: same decisions, all converged
+        r2 = lb.results()
+        lanes_agree = lanes_agree and bool(np.array_equal(r2["S"], res["S"]) and
+                                           np.array_equal(r2["status"], res["status"]))
+    ok = bool((res["status"] > 0).all()) and lanes_agree
     stats = res["stats"]
     read_bytes = int(stats["read_bytes"].sum())     # bytes this kernel's formulation has to read
     dense_bytes = int(stats["alg_bytes"].sum())     # bytes of the reference's dense formulation
@@ -116,7 +142,19 @@ def main():
             torch.cuda.synchronize(dev)
             ms.append(ctx.last_kernel_ms())
         return ms
-    k_ms = float(np.mean(timed_launches(3) + [last_kernel_ms]))
+    # (single launches on one stream: the kernel's own duration.  With several lanes the launches of the timed
+    #  region overlap, and a launch's begin-to-end time then contains slot-sharing with its neighbours.)
+    iso = timed_launches(4)
+    k_ms = float(np.mean(iso if nlanes > 1 else iso[:3] + [last_kernel_ms]))
+    # the same K steps on ONE stream, for comparison with the pipelined figure
+    single = None
+    if nlanes > 1:
+        torch.cuda.synchronize(dev)
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            batch.solve()
+        torch.cuda.synchronize(dev)
+        single = (time.perf_counter() - ts) / args.steps
     # the same kernel with the gamma pass reading EVERY column of V, as the reference's dense
     # V[B,F]*alpha + V[B,B]*zB does (SSQP.jl:352): the HBM-bound formulation, timed beside the default one
     dense = None
@@ -156,6 +194,13 @@ def main():
                        "qps_per_gpu": P, "parallelism": "one QP per workgroup, batch sharded over %d GPU(s)" % world},
             "iters_to_kkt": {"mean": float(iters.mean()), "max": int(iters.max()), "min": int(iters.min())},
             "all_converged": ok,
+            "pipeline": {"streams": nlanes, "lanes_agree": lanes_agree,
+                         "kernel_ms_last_timed_launch": last_kernel_ms,
+                         "single_stream_ms_per_step": None if single is None else 1e3 * single,
+                         "single_stream_qps": None if single is None else P / single,
+                         "note": "steps are independent batches issued round-robin on `streams` HIP streams (one "
+                                 "context per lane, shared inputs, per-lane outputs): the drain of one launch overlaps "
+                                 "the ramp-up of the next; every step solves all its QPs from (x0, S0)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "ssqp_solve_kernel", "kernel_ms": k_ms, "alg_bytes_per_launch": read_bytes,

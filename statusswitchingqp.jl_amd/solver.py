@@ -246,6 +246,25 @@ class DeviceBatch:
         self.trace = torch.zeros((self.P, max(self.ntrace, 1), 4), dtype=torch.int32, device=dev)
         torch.cuda.synchronize(dev)
 
+    def twin(self, ctx):
+        """A second launch lane over the SAME inputs (V, A, G, ..., S0, x0 are shared, not copied) with its own
+        context (workspace, work counter) and its own outputs: batches issued on different HIP streams can then
+        overlap -- the drain of one launch (workgroups finish at different times) with the ramp-up of the next."""
+        torch = self.torch
+        o = object.__new__(DeviceBatch)
+        o.torch, o.ctx = torch, ctx
+        o.P, o.N, o.M, o.J = self.P, self.N, self.M, self.J
+        o.t, o.S0, o.x0 = self.t, self.S0, self.x0
+        o.S = torch.empty_like(self.S0)
+        o.z = torch.zeros_like(self.z)
+        o.status = torch.zeros_like(self.status)
+        o.detail = torch.zeros_like(self.detail)
+        o.stats = torch.zeros_like(self.stats)
+        o.ntrace = self.ntrace
+        o.trace = torch.zeros_like(self.trace)
+        torch.cuda.synchronize(self.S0.device)
+        return o
+
     @staticmethod
     def _ptr(t):
         return C.c_void_p(t.data_ptr()) if t.numel() else None

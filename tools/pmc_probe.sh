@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu --skip-dense > $OUT/p$i.log 2>&1 || { tail -5 $OUT/p$i.log; exit 1; }
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu --skip-dense --streams 1 > $OUT/p$i.log 2>&1 || { tail -5 $OUT/p$i.log; exit 1; }
 done
 python3 - <<PY
 import csv,glob,collections
