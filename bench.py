@@ -204,9 +204,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "ssqp_solve_kernel", "kernel_ms": k_ms, "alg_bytes_per_launch": read_bytes,
-                         "note": "default formulation: kept LDL' factor (append/delete) and a gamma pass that skips the "
-                                 "columns of V whose weight is exactly 0 (bound variables at d=0): the loop is "
-                                 "latency-bound (dependent single-wavefront chains), not HBM-bound"},
+                         "note": "default formulation: kept LDL' factor (append/delete), hB+q and bE cached across "
+                                 "passes, gamma pass over the free columns only: the loop is latency-bound (dependent "
+                                 "single-wavefront chains), not HBM-bound; kernel_ms = single launches timed by "
+                                 "their own HIP events"},
             "roofline_dense_formulation": None if dense is None else {
                 "bound": "hbm", "achieved": dense["read"] / (dense["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": dense["read"] / (dense["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
