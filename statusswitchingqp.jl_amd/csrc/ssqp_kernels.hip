@@ -587,6 +587,7 @@ __device__ __forceinline__ int compact_nonzero(const double *w, int N, bool dens
 // at once (ired[CNT0 + chunk*NW + wave]) and each thread derives its offsets from them.  Also scatters zB:
 // zm[i] = z[i] for bound variables, 0 for free ones (SSQP.jl:286).  The caller's next barrier publishes the lists.
 constexpr int CNT0 = 2 * NW + 16;  // first count slot in ired
+constexpr int ROWS_DIRTY = 2 * NW + 15;  // ired slot: an inequality changed status since the row lists were formed
 constexpr int HB_DIRTY = 2 * NW + 13;  // ired slot: a bound variable with z != 0 changed status since hq was formed
 template <int MPT>
 __device__ __forceinline__ int compact_free(const Lds &L, int N) {
@@ -2532,6 +2533,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             for (int o = tid; o < JO; o += NT)
                 if (L.lin[o] < inf && !(L.lin[o] - L1 > tol)) {
                     L.S[N + L.iO[o]] = SSQP_EO;
+                    L.ired[ROWS_DIRTY] = 1;
                     firstId = min(firstId, N + L.iO[o] + 1);
                 }
             if (trace) {
@@ -2679,6 +2681,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         if (tid == 0) {
             L.S[ev.ord] = (ev.ord < N) ? SSQP_IN : SSQP_OE;
             if (ev.ord < N && L.z[ev.ord < N ? ev.ord : 0] != 0.0) L.ired[HB_DIRTY] = 1;  // B loses a nonzero column
+            if (ev.ord >= N) L.ired[ROWS_DIRTY] = 1;
             if (trace) *trace = ssqp_trace{K, W, 2, ev.ord + 1};
         }
         __syncthreads();
@@ -2754,7 +2757,10 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
     C.hbValid = false;
     C.yValid = 0;
     C.yW0 = -1;
-    if (tid == 0) L.ired[HB_DIRTY] = 0;
+    if (tid == 0) {
+        L.ired[HB_DIRTY] = 0;
+        L.ired[ROWS_DIRTY] = 1;
+    }
     if (P.incremental) {
         int rc = INC_KMAX;
         for (; rc >= 16; rc -= 2) {
@@ -2827,7 +2833,8 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
         if (K > C.maxK) C.maxK = K;
 
         // ---- active / inactive inequality lists  (SSQP.jl:288-289) ----
-        if (wave == 0) {  // J is small: one wavefront, ballot compaction keeps the order
+        // (rebuilt only when an inequality changed status since they were formed: ROWS_DIRTY)
+        if (wave == 0 && L.ired[ROWS_DIRTY] != 0) {  // J is small: one wavefront, ballot compaction keeps the order
             int nE = M, nO = 0;
             for (int c0 = 0; c0 < J; c0 += 64) {
                 const int j = c0 + lane;
@@ -2843,6 +2850,7 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
             if (lane == 0) {
                 L.ired[2 * NW] = nE;
                 L.ired[2 * NW + 1] = nO;
+                L.ired[ROWS_DIRTY] = 0;
             }
         }
         __syncthreads();  // pos, idx, zm (zB scattered) and the row lists are published
