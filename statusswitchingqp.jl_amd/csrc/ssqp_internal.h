@@ -48,7 +48,7 @@ struct SolveParams {
 // doubles), then the integer regions (offsets in bytes).
 struct LdsLayout {
     int z, zm, gam, hq, arena, bE, aL, tv, dcol, lin, bEall, red;  // in doubles
-    int S_bytes, ired_bytes, pos_bytes, idx_bytes, perm_bytes, rowsE_bytes, ra_bytes, iO_bytes, fpos_bytes, ordl_bytes, ytag_bytes;
+    int S_bytes, ired_bytes, pos_bytes, idx_bytes, perm_bytes, rowsE_bytes, ra_bytes, iO_bytes, fpos_bytes, ordl_bytes, ytag_bytes, evt_bytes;
     int total_bytes;
 };
 
@@ -65,6 +65,7 @@ __host__ __device__ inline int lds_fixed_bytes(int N, int M, int J) {
     bytes += align_up(2 * (N + M + J + 4), 8);   // perm (column list of the AXPY pass: N columns + constraint rows + q)
     bytes += 3 * align_up(2 * (M + J + 2), 8);   // rowsE, ra, iO
     bytes += 32;                                 // ytag (row ids of the kept border columns)
+    bytes += 16 * 8 + 16 * 4;                    // evt: variables that entered B with a nonzero value in this pass
     return bytes;
 }
 
@@ -96,6 +97,7 @@ __host__ __device__ inline LdsLayout lds_layout(int N, int M, int J, int arenaCa
     l.fpos_bytes = b; b += align_up(2 * (N + 2), 8);
     l.ordl_bytes = b; b += align_up(2 * (N + 2), 8);
     l.ytag_bytes = b; b += 32;
+    l.evt_bytes = b; b += 16 * 8 + 16 * 4;
     l.total_bytes = b;
     return l;
 }

@@ -255,6 +255,8 @@ struct Lds {
     int *ired;                           // 2*NW + 8
     int16_t *pos, *idx, *perm, *rowsE, *ra, *iO, *fpos, *ordl;
     int16_t *ytag;                       // row id behind each kept border column (16 entries)
+    double *evtz;                        // up to 16 (value, index) events of a pass: variables that became bound at a
+    int *evti;                           //   nonzero value (hq and bEall are updated by their columns, see bound_event)
 };
 
 __device__ __forceinline__ double block_max(double v, const Lds &L) {
@@ -587,6 +589,8 @@ __device__ __forceinline__ int compact_nonzero(const double *w, int N, bool dens
 // at once (ired[CNT0 + chunk*NW + wave]) and each thread derives its offsets from them.  Also scatters zB:
 // zm[i] = z[i] for bound variables, 0 for free ones (SSQP.jl:286).  The caller's next barrier publishes the lists.
 constexpr int CNT0 = 2 * NW + 16;  // first count slot in ired
+constexpr int EVT_MAX = 16;
+constexpr int HQ_CHANGED = 2 * NW + 8;  // ired slot: hq was updated by a status switch since the border columns were formed
 constexpr int ROWS_DIRTY = 2 * NW + 15;  // ired slot: an inequality changed status since the row lists were formed
 constexpr int HB_DIRTY = 2 * NW + 13;  // ired slot: a bound variable with z != 0 changed status since hq was formed
 template <int MPT>
@@ -1736,6 +1740,25 @@ __device__ __forceinline__ bool small_spd_solve(const double *H, const double *r
     return ok;
 }
 
+// zB[j] changed by dz (a variable entered B at a nonzero value, or left it): the cached hq = V[:,nz(zB)] zB + q and
+// bEall = rhs - [A;G] zB follow by ONE column each (hq += V[:,j] dz, bEall -= [A;G][:,j] dz) instead of being
+// re-evaluated from every nonzero column / every constraint row in the next pass.  All threads; N even, N <= 512.
+__device__ __forceinline__ void bound_event(const Lds &L, const double *__restrict__ V, const double *__restrict__ Ct,
+                                            int N, int MJ, int j, double dz) {
+    const int tid = threadIdx.x;
+    const int r = 2 * tid;
+    const double2 v = *reinterpret_cast<const double2 *>(V + (size_t)j * N + (r < N ? r : 0));
+    const double cj = Ct[(size_t)(tid < MJ ? tid : 0) * N + j];
+    if (r < N) {
+        double2 hv = *reinterpret_cast<double2 *>(L.hq + r);
+        hv.x = fma(v.x, dz, hv.x);
+        hv.y = fma(v.y, dz, hv.y);
+        *reinterpret_cast<double2 *>(L.hq + r) = hv;
+    }
+    if (tid < MJ) L.bEall[tid] = fma(-cj, dz, L.bEall[tid]);
+    if (tid == 0) L.ired[HQ_CHANGED] = 1;  // the border column L^-1 c kept from the last pass is stale
+}
+
 // ------------------------------------------------------------------ the loop
 struct ProbCtx {
     int N, M, J, MJ;
@@ -1830,6 +1853,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         (long)2 * N + (long)W0 * (K + 1) + 8 <= C.scrCap) {
         PHASE(C, 1);
         const bool needHB = C.dense || !C.hbValid || (L.ired[HB_DIRTY] != 0);
+        const bool hqChanged = L.ired[HQ_CHANGED] != 0;  // (read here, reset after the join: barriers in between)
         // do the kept border columns Y still belong to the same constraint rows, slot by slot?
         bool tagsSame = (W0 == C.yW0);
         {
@@ -2003,7 +2027,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         {
             const int minDel = uni(L.ired[2 * NW + 14]);
             if (minDel < r0) r0 = minDel;
-            if (needHB || !tagsSame || r0 > K) r0 = 0;
+            if (needHB || !tagsSame || r0 > K || hqChanged) r0 = 0;
         }
         const bool rowMode = (r0 > 0) && (K - r0 <= 2);
         if (!rowMode) r0 = 0;
@@ -2032,7 +2056,10 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
                 for (int i = tid; i < N; i += NT) L.hq[i] = (ar[i] + ar[N + i]) + q[i];
             }
         }
-        if (tid == 0) L.ired[HB_DIRTY] = 0;
+        if (tid == 0) {
+            L.ired[HB_DIRTY] = 0;
+            L.ired[HQ_CHANGED] = 0;
+        }
         C.hbValid = true;
         if (tid <= Wspec) L.perm[tid] = (tid < Wspec) ? L.ra[tid] : (int16_t)W0;  // physical right-hand sides
         __syncthreads();
@@ -2434,6 +2461,8 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         C.sK3 += k * k * k;
     }
 
+    // the caches hq / bEall are live (front half, all rows cached): status switches update them by one column
+    const bool evtOK = (VEC == 2) && frontDone && !C.dense && C.hbValid && (MJ <= RF_ROWS);
     PHASE(C, 8);
     if (pinf > tolG && !anyNan) {  // ------------------------ aStep!  SSQP.jl:61-134
         // inactive inequalities: zo = g - G z, po = G[:,F] p   (:78-89)
@@ -2525,7 +2554,17 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
                         L.S[i] = up ? SSQP_UP : SSQP_DN;
                         zn = up ? ureg[m] : dreg[m];
                         firstId = min(firstId, i + 1);
-                        if (zn != 0.0) L.ired[HB_DIRTY] = 1;  // B gains a column with a nonzero weight
+                        if (zn != 0.0) {  // B gains a column with a nonzero weight
+                            if (evtOK) {
+                                const int slot = atomicAdd(&L.ired[2 * NW + 9], 1);
+                                if (slot < EVT_MAX) {
+                                    L.evti[slot] = i;
+                                    L.evtz[slot] = zn;
+                                }
+                            } else {
+                                L.ired[HB_DIRTY] = 1;
+                            }
+                        }
                     }
                     L.z[i] = zn;
                 }
@@ -2542,6 +2581,28 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
                 if (tid == 0) *trace = ssqp_trace{K, W, 1, (int)f.v};
             }
             __syncthreads();
+            if (evtOK) {  // the caches follow the newly bound variables, by increasing index (deterministic order)
+                const int ne = L.ired[2 * NW + 9];
+                if (ne > EVT_MAX) {
+                    if (tid == 0) L.ired[HB_DIRTY] = 1;
+                } else {
+                    int last = -1;
+                    for (int e = 0; e < ne; ++e) {
+                        int best = 0x7fffffff, be = 0;
+                        for (int f = 0; f < ne; ++f) {
+                            const int iv = L.evti[f];
+                            if (iv > last && iv < best) {
+                                best = iv;
+                                be = f;
+                            }
+                        }
+                        bound_event(L, V, Ct, N, MJ, best, L.evtz[be]);
+                        last = best;
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) L.ired[2 * NW + 9] = 0;
+            }
             return ACT_CONTINUE;
         }
         // full step: z[F] = alpha  (:130)
@@ -2680,9 +2741,13 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     if (ev.v < inf) {  // release the single tightest one (:175-184)
         if (tid == 0) {
             L.S[ev.ord] = (ev.ord < N) ? SSQP_IN : SSQP_OE;
-            if (ev.ord < N && L.z[ev.ord < N ? ev.ord : 0] != 0.0) L.ired[HB_DIRTY] = 1;  // B loses a nonzero column
+            if (!evtOK && ev.ord < N && L.z[ev.ord < N ? ev.ord : 0] != 0.0) L.ired[HB_DIRTY] = 1;  // B loses a nonzero column
             if (ev.ord >= N) L.ired[ROWS_DIRTY] = 1;
             if (trace) *trace = ssqp_trace{K, W, 2, ev.ord + 1};
+        }
+        if (evtOK && ev.ord < N) {  // B loses a column: the caches follow (uniform)
+            const double zr = L.z[ev.ord];
+            if (zr != 0.0) bound_event(L, V, Ct, N, MJ, ev.ord, -zr);  // (hq was last read before the gamma pass's barrier)
         }
         __syncthreads();
         return ACT_CONTINUE;
@@ -2760,6 +2825,8 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
     if (tid == 0) {
         L.ired[HB_DIRTY] = 0;
         L.ired[ROWS_DIRTY] = 1;
+        L.ired[2 * NW + 9] = 0;
+        L.ired[HQ_CHANGED] = 0;
     }
     if (P.incremental) {
         int rc = INC_KMAX;
@@ -2968,6 +3035,8 @@ __global__ __launch_bounds__(NT, WPS) void ssqp_solve_kernel(SolveParams P) {
         L.fpos = reinterpret_cast<int16_t *>(smem + lay.fpos_bytes);
         L.ordl = reinterpret_cast<int16_t *>(smem + lay.ordl_bytes);
         L.ytag = reinterpret_cast<int16_t *>(smem + lay.ytag_bytes);
+        L.evtz = reinterpret_cast<double *>(smem + lay.evt_bytes);
+        L.evti = reinterpret_cast<int *>(smem + lay.evt_bytes + 16 * 8);
     }
     double *garena = P.gscratch + (size_t)blockIdx.x * P.gscratchStride;
     for (;;) {
