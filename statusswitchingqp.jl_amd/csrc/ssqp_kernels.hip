@@ -1848,6 +1848,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     // wavefront-specialised front half (see inc_sync_w0): needs the AXPY loads (N even, N <= 512), a rank filter
     // that fits in registers, and room in the scratch arena for two partial vectors plus X
     bool frontDone = false;
+    bool cachedRows = false;  // (byte accounting: the constraint rows are not swept in this pass)
     int Wspec = W0;
     if (useInc && VEC == 2 && W0 <= RF_ROWS && (W0 <= 4 ? K + 1 <= 256 : K + 1 <= 192) &&
         (long)2 * N + (long)W0 * (K + 1) + 8 <= C.scrCap) {
@@ -2017,6 +2018,12 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         }
         Wspec = L.ired[2 * NW + 4];
         C.sRead += 64ll * L.ired[2 * NW + 11] * K + 8ll * N * L.ired[2 * NW + 12] - 8ll * N * K;
+        if (MJ <= RF_ROWS) {  // E rows: a W0 x K gather (one 64-byte sector per entry); the full rows (and q) are swept
+                              // only when bE / hq are re-evaluated.  (The common line below adds 8*MJ*N: taken back
+                              // here; aStep! adds the rows it reads.)
+            C.sRead += 64ll * W0 * K - 8ll * MJ * N + (needHB ? 8ll * MJ * N + 8ll * N : 0ll);
+            cachedRows = true;
+        }
         // border right-hand sides AE' in factor order: from X in LDS when the register rank filter left it intact,
         // else (the LDS filter eliminated in place) gathered again from the constraint rows
         const bool xKept = !(W0 > 4 && K + 1 > 128);
@@ -2464,6 +2471,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
     // the caches hq / bEall are live (front half, all rows cached): status switches update them by one column
     const bool evtOK = (VEC == 2) && frontDone && !C.dense && C.hbValid && (MJ <= RF_ROWS);
     PHASE(C, 8);
+    if (cachedRows && pinf > tolG && !anyNan) C.sRead += 8ll * N * JO;  // rows of the inactive inequalities
     if (pinf > tolG && !anyNan) {  // ------------------------ aStep!  SSQP.jl:61-134
         // inactive inequalities: zo = g - G z, po = G[:,F] p   (:78-89)
         SUBPHASE_DECL(tast);
@@ -2597,6 +2605,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
                             }
                         }
                         bound_event(L, V, Ct, N, MJ, best, L.evtz[be]);
+                        C.sRead += 8ll * N + 64ll * MJ;
                         last = best;
                     }
                 }
@@ -2747,7 +2756,10 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         }
         if (evtOK && ev.ord < N) {  // B loses a column: the caches follow (uniform)
             const double zr = L.z[ev.ord];
-            if (zr != 0.0) bound_event(L, V, Ct, N, MJ, ev.ord, -zr);  // (hq was last read before the gamma pass's barrier)
+            if (zr != 0.0) {  // (hq was last read before the gamma pass's barrier)
+                bound_event(L, V, Ct, N, MJ, ev.ord, -zr);
+                C.sRead += 8ll * N + 64ll * MJ;
+            }
         }
         __syncthreads();
         return ACT_CONTINUE;
