@@ -290,3 +290,30 @@ def test_shared_v_batch_efficient_frontier_style(pkg, orc):
     zo, So, sto, _, _ = oracle_batch(orc, full, S0, x0)
     assert_parity(r["z"], r["S"], r["status"], zo, So, sto)
     assert len(set(map(tuple, r["S"]))) > 3       # the frontier really moves through different active sets
+
+
+def test_launch_lanes_overlap_and_agree(pkg, orc):
+    """three launch lanes (one context and one HIP stream each, shared inputs, own outputs -- what bench.py uses to
+    overlap the drain of one batch with the start of the next): overlapping launches give the decisions of a
+    serial launch, and those of the oracle"""
+    import torch
+    cfg = pkg.GenConfig(96, 1, 6, 192, 1e-3, 0.08, 1.02, 0.15)
+    b0, prob, x0, S0 = pkg.DeviceBatch.generated(cfg, 600, 777)
+    dev = b0.S.device
+    lanes = [(b0, torch.cuda.current_stream(dev))]
+    for _ in range(2):
+        lanes.append((b0.twin(pkg.Context(dev.index)), torch.cuda.Stream(dev)))
+    for rep in range(2):
+        for b, st in lanes:
+            with torch.cuda.stream(st):
+                b.solve()
+    torch.cuda.synchronize(dev)
+    ref = lanes[0][0].results()
+    for b, _ in lanes[1:]:
+        r = b.results()
+        assert np.array_equal(r["S"], ref["S"]) and np.array_equal(r["status"], ref["status"])
+        assert np.array_equal(r["z"], ref["z"])
+    full = dict(prob)
+    full["V"] = b0.t["V"].cpu().numpy()
+    zo, So, sto, _, _ = oracle_batch(orc, full, S0, x0)
+    assert_parity(ref["z"], ref["S"], ref["status"], zo, So, sto)
