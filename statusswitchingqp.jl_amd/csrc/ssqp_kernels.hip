@@ -8,13 +8,16 @@
 //   compaction      F = (S .== IN), index lists                      SSQP.jl:276-289
 //   factor sync     the LDL' factor of V[F,F] is KEPT across passes: append a released variable,
 //                   delete a blocked one (replaces inv(cholesky(V[F,F])) from scratch, SSQP.jl:322)
-//   E-row sweep     bE = [b; g[Eg]] - AB*zB, X = [AE bE]             SSQP.jl:290-295
+//   E rows          bE = [b; g[Eg]] - AB*zB (kept for every row, follows zB by one column of [A;G] per status
+//                   switch), X = [AE bE] by a K x W0 gather         SSQP.jl:290-295
 //   rank filter     getRowsGJr(X, tol), operation for operation      utils.jl:49-86
-//   c               V[:,nz(zB)] zB in AXPY form, c = hB[F] + q[F]    SSQP.jl:323-324
-//   KKT solve       forward substitution of the border [AE' c], Schur system
-//                   (AE V_FF^-1 AE') lambda = bE + AE V_FF^-1 c, one back substitution   SSQP.jl:325-332
+//   c               hq = V[:,nz(zB)] zB + q kept in LDS, follows zB by one column of V per status switch;
+//                   c = hq[F]                                        SSQP.jl:323-324
+//   KKT solve       forward substitution of the border [AE' c] (only the appended row when nothing else
+//                   changed), Schur system (AE V_FF^-1 AE') lambda = bE + AE V_FF^-1 c,
+//                   one back substitution                            SSQP.jl:325-332
 //   aStep!          ratio test as workgroup min-reduction            SSQP.jl:61-134
-//   gamma pass      V[:,nz] [alpha; zB], zero-weight columns skipped SSQP.jl:351-352
+//   gamma pass      V[:,F] alpha + AB' alphaL (AXPY) + hq            SSQP.jl:351-352
 //   KKTchk!         (value, order) argmin                            SSQP.jl:136-188
 //   polishSz!                                                        SSQP.jl:10-32
 //   freeK!          K == 0 pass                                      SSQP.jl:35-59
