@@ -8,6 +8,9 @@ import os
 import numpy as np
 import pytest
 
+# SSQP_TEST_SEED=<n> shifts the seeds of the randomised shape tests (extra sweeps on a GPU box)
+SEED_SHIFT = int(os.environ.get("SSQP_TEST_SEED", "0"))
+
 from conftest import assert_parity, colmajor, oracle_batch
 
 pytestmark = pytest.mark.gpu
@@ -231,7 +234,7 @@ def _mutate(prob, rng, kind):
 def test_random_shapes_and_bounds(pkg, orc, kind):
     """many small random problems of mixed shapes; every one must match the oracle decision for decision"""
     import zlib
-    rng = np.random.default_rng(zlib.crc32(kind.encode()))
+    rng = np.random.default_rng(zlib.crc32(kind.encode()) + SEED_SHIFT)
     shapes = [(24, 1, 0), (40, 1, 3), (57, 2, 4), (64, 1, 6), (96, 3, 8), (130, 1, 10), (150, 2, 5), (200, 1, 2)]
     _check_shapes(pkg, orc, kind, rng, shapes, 12, 40)
 
@@ -241,7 +244,7 @@ def test_many_inequalities_and_wide_shapes(pkg, orc, kind):
     """more constraint rows than the cached-row batch holds (M+J > 12: full row sweeps, possibly more than 12 active
     rows -> the workgroup rank filter and the from-scratch factorisation), and N up to 512 with up to 12 rows"""
     import zlib
-    rng = np.random.default_rng(zlib.crc32(("wide" + kind).encode()))
+    rng = np.random.default_rng(zlib.crc32(("wide" + kind).encode()) + SEED_SHIFT)
     shapes = [(80, 1, 14), (120, 2, 20), (96, 1, 12), (256, 1, 11), (384, 2, 9), (512, 1, 6)]
     _check_shapes(pkg, orc, kind, rng, shapes, 6, 20)
 
