@@ -78,7 +78,9 @@ typedef struct ssqp_stats {
     int64_t alg_flops;  /* sum_i K^3 + 4K^2W + 2K^2 + 2R^2 + 4RK + ... */
     int64_t sum_k3;     /* sum_i K^3 */
     int32_t max_k;      /* largest free set seen */
-    int32_t path;       /* bit0: LDS factor path used, bit1: global-scratch path used */
+    int32_t path;       /* bit0: LDS factor path used, bit1: global-scratch path, bit2: kept-factor engine, bit3: kept
+                           factor migrated to the global arena, bit4: wavefront-per-QP kernel, bit5: handed over
+                           from the wavefront kernel to the workgroup kernel */
 } ssqp_stats;
 
 /* one record per loop pass when tracing is requested */
@@ -97,6 +99,20 @@ typedef struct ssqp_ctx ssqp_ctx;
 int ssqp_ctx_create(int device, ssqp_ctx **out);
 int ssqp_ctx_destroy(ssqp_ctx *ctx);
 const char *ssqp_last_error(const ssqp_ctx *ctx);
+/* Per-context switches (never read from the environment; a context belongs to one host thread at a time).
+ * The reference's Settings (src/types.jl:390-397) stay free of backend fields.
+ *   "wave_kernel"     1 (default): QPs of a shape the wavefront-per-QP kernel takes (N even <= 512, M+J <= 11)
+ *                     run there and are handed over to the workgroup kernel only when their free set outgrows
+ *                     it; 0: workgroup kernel only
+ *   "wave_qp_per_cu"  4..8 QPs (wavefronts) per CU for that kernel (default 4); fewer = larger factor capacity
+ *   "incremental"     1 (default): keep the LDL' factor of V[F,F] across passes; 0: refactor in every pass like
+ *                     SSQP.jl:322 (workgroup kernel)
+ *   "dense_gamma"     1: the reference's dense formulation (from-scratch factor, gamma pass over all N columns,
+ *                     SSQP.jl:322,352) -- the HBM roofline measurement; default 0
+ *   "wg_per_cu"       workgroups per CU of the workgroup kernel: 0 = automatic (default), 1, 2
+ * Unknown names / out-of-range values: SSQP_ERR_ARG. */
+int ssqp_ctx_set_option(ssqp_ctx *ctx, const char *name, int value);
+int ssqp_ctx_get_option(ssqp_ctx *ctx, const char *name, int *value);
 /* library/version string, safe without a GPU */
 const char *ssqp_version(void);
 /* Settings{Float64}() defaults (types.jl:401-408) */

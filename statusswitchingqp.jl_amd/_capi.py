@@ -55,6 +55,8 @@ SIGNATURES = {
     "ssqp_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "ssqp_ctx_destroy": (C.c_int, [_vp]),
     "ssqp_last_error": (C.c_char_p, [_vp]),
+    "ssqp_ctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "ssqp_ctx_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int)]),
     "ssqp_version": (C.c_char_p, []),
     "ssqp_default_settings": (None, [C.POINTER(CSettings)]),
     "ssqp_solve_f64": (C.c_int, [_vp] + [C.c_int] * 3 + [_vp] * 8 + [_vp, _vp, _vp, C.POINTER(CSettings), _lp, _ip]),

@@ -26,8 +26,14 @@ struct ssqp_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     std::string err;
+    // options (ssqp_ctx_set_option): algorithm switches are per context, never read from the environment
+    int optWgPerCU = 0;      // 0 = automatic
+    int optDenseGamma = 0;   // 1: dense (reference-shaped) formulation -- roofline measurements
+    int optIncremental = 1;  // 0: refactor V[F,F] from scratch in every pass
+    int optWaveKernel = 1;   // 0: never use the wavefront-per-QP kernel
+    int optWaveQPC = 4;      // QPs (wavefronts) per CU of the wavefront kernel: 4..8
     // grow-only device workspaces
-    DevBuf Ct, rhs, queue, gscratch;
+    DevBuf Ct, rhs, queue, gscratch, fbList, fbIter, wscratch;
     // staging buffers of the host-pointer entry points
     DevBuf hV, hA, hG, hq, hb, hg, hd, hu, hS, hx0, hz, hstatus, hdetail, hstats;
 };
@@ -105,7 +111,7 @@ int ssqp_ctx_destroy(ssqp_ctx *c) {
     if (!c) return SSQP_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->Ct, &c->rhs, &c->queue, &c->gscratch, &c->hV, &c->hA, &c->hG, &c->hq, &c->hb, &c->hg,
+    for (DevBuf *b : {&c->Ct, &c->rhs, &c->queue, &c->gscratch, &c->fbList, &c->fbIter, &c->wscratch, &c->hV, &c->hA, &c->hG, &c->hq, &c->hb, &c->hg,
                       &c->hd, &c->hu, &c->hS, &c->hx0, &c->hz, &c->hstatus, &c->hdetail, &c->hstats})
         release(*b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -116,6 +122,38 @@ int ssqp_ctx_destroy(ssqp_ctx *c) {
 }
 
 const char *ssqp_last_error(const ssqp_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+static int *option_slot(ssqp_ctx *c, const char *name) {
+    if (!c || !name) return nullptr;
+    if (!std::strcmp(name, "wg_per_cu")) return &c->optWgPerCU;
+    if (!std::strcmp(name, "dense_gamma")) return &c->optDenseGamma;
+    if (!std::strcmp(name, "incremental")) return &c->optIncremental;
+    if (!std::strcmp(name, "wave_kernel")) return &c->optWaveKernel;
+    if (!std::strcmp(name, "wave_qp_per_cu")) return &c->optWaveQPC;
+    return nullptr;
+}
+int ssqp_ctx_set_option(ssqp_ctx *c, const char *name, int value) {
+    int *slot = option_slot(c, name);
+    if (!slot) {
+        if (c) c->err = std::string("unknown option ") + (name ? name : "(null)");
+        return SSQP_ERR_ARG;
+    }
+    if ((slot == &c->optWgPerCU && (value < 0 || value > ssqp::MAX_WG_PER_CU)) ||
+        (slot == &c->optWaveQPC && (value < 1 || value > 8)) ||
+        ((slot == &c->optDenseGamma || slot == &c->optIncremental || slot == &c->optWaveKernel) &&
+         (value != 0 && value != 1))) {
+        c->err = std::string("option value out of range: ") + name;
+        return SSQP_ERR_ARG;
+    }
+    *slot = value;
+    return SSQP_OK;
+}
+int ssqp_ctx_get_option(ssqp_ctx *c, const char *name, int *value) {
+    int *slot = option_slot(c, name);
+    if (!slot || !value) return SSQP_ERR_ARG;
+    *value = *slot;
+    return SSQP_OK;
+}
 
 int ssqp_sync(ssqp_ctx *c, void *stream) {
     if (!c) return SSQP_ERR_ARG;
@@ -169,18 +207,34 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
             break;
         }
     }
-    if (const char *e = getenv("SSQP_WG_PER_CU")) {
-        const int w = atoi(e);
-        if (w >= 1 && w <= ssqp::MAX_WG_PER_CU) wgPerCU = w;
-    }
+    if (c->optWgPerCU >= 1) wgPerCU = c->optWgPerCU;
     if (N > 512 && (N & 1) == 0) wgPerCU = 1;  // the wide-accumulator kernels are built for one workgroup per CU
     const int ldsPerWG = (ssqp::LDS_BYTES / wgPerCU) / 1024 * 1024;
     int grid = c->numCU * wgPerCU;
     if (grid > nprob) grid = nprob;
     if (grid < 1) grid = 1;
     const size_t gstride = ssqp::global_arena_doubles(N, M, J);
+    // the wavefront-per-QP kernel takes the shapes it is built for (N even <= 512, M + J <= 11) in the default
+    // formulation; QPs it hands over (free set beyond its factor capacity) continue in the workgroup kernel
+    const bool useWave = c->optWaveKernel && c->optIncremental && !c->optDenseGamma && ssqp::wave_kernel_applies(N, M, J);
+    int waveGrid = 0, waveRC = 0, waveLds = 0;
+    size_t wstride = 0;
+    if (useWave) {
+        const int qpc = c->optWaveQPC;
+        const int perWave = (ssqp::LDS_BYTES / qpc) / 256 * 256;
+        waveRC = 127;
+        while (waveRC > 8 && ssqp::wave_lds_bytes(waveRC) > perWave) --waveRC;
+        if (waveRC > N) waveRC = N;
+        waveLds = ssqp::wave_lds_bytes(waveRC);
+        waveGrid = c->numCU * qpc;
+        if (waveGrid > nprob) waveGrid = nprob;
+        wstride = ssqp::wave_scratch_doubles(N, M, J);
+    }
     if (!ensure(c, c->Ct, (size_t)nprob * MJ * N * 8) || !ensure(c, c->rhs, (size_t)nprob * MJ * 8) ||
         !ensure(c, c->queue, 64) || !ensure(c, c->gscratch, (size_t)grid * gstride * 8))
+        return SSQP_ERR_ALLOC;
+    if (useWave && (!ensure(c, c->fbList, (size_t)nprob * 4) || !ensure(c, c->fbIter, (size_t)nprob * 8) ||
+                    !ensure(c, c->wscratch, (size_t)waveGrid * wstride * 8)))
         return SSQP_ERR_ALLOC;
 
     ssqp::SolveParams P;
@@ -201,13 +255,17 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
     P.queue = (unsigned int *)c->queue.p;
     P.gscratch = (double *)c->gscratch.p;
     P.gscratchStride = gstride;
-    {
-        const char *e = getenv("SSQP_DENSE_GAMMA");
-        P.denseGamma = (e && atoi(e) != 0) ? 1 : 0;
-        const char *f = getenv("SSQP_INCREMENTAL");
-        P.incremental = (f && atoi(f) == 0) ? 0 : 1;
-        if (P.denseGamma) P.incremental = 0;  // the dense-formulation run is the from-scratch, reference-shaped pass
-    }
+    P.denseGamma = c->optDenseGamma;
+    P.incremental = c->optDenseGamma ? 0 : c->optIncremental;  // the dense run is the from-scratch, reference-shaped pass
+    // queue words: [0] work counter of the wavefront kernel, [1] of the workgroup kernel, [2] hand-over count
+    P.fbCount = (unsigned int *)c->queue.p + 2;
+    P.fbList = (int *)c->fbList.p;
+    P.fbIter = (long long *)c->fbIter.p;
+    P.resume = 0;
+    P.wscratch = (double *)c->wscratch.p;
+    P.wscratchStride = wstride;
+    P.waveLdsBytes = waveLds;
+    P.waveRC = waveRC;
     P.arenaCap = ((ldsPerWG - fixed - 64) / 16) * 2;
     if (P.arenaCap < 0) P.arenaCap = 0;
     const ssqp::LdsLayout lay = ssqp::lds_layout(N, M, J, P.arenaCap);
@@ -221,6 +279,12 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
                       (double *)c->Ct.p, (double *)c->rhs.p, s);
     if (!hip_ok(c, hipGetLastError(), "prep launch")) return SSQP_ERR_HIP;
     if (!hip_ok(c, hipEventRecord(c->ev0, s), "hipEventRecord")) return SSQP_ERR_HIP;
+    if (useWave) {
+        P.queue = (unsigned int *)c->queue.p;
+        if (!hip_ok(c, ssqp::launch_solve_wave(P, waveGrid, s), "wave solve launch")) return SSQP_ERR_HIP;
+        P.queue = (unsigned int *)c->queue.p + 1;
+        P.resume = 1;  // (a grid that finds the hand-over list empty exits at once)
+    }
     if (!hip_ok(c, ssqp::launch_solve(P, grid, (size_t)lay.total_bytes, wgPerCU, s), "solve launch")) return SSQP_ERR_HIP;
     if (!hip_ok(c, hipEventRecord(c->ev1, s), "hipEventRecord")) return SSQP_ERR_HIP;
     c->timed = true;

@@ -42,6 +42,19 @@ struct SolveParams {
     int arenaCap;            // doubles in the LDS arena
     int denseGamma;          // 1: the gamma pass reads every column of V (dense formulation, for roofline runs)
     int incremental;         // 1: keep the LDL' factor across passes (append/delete) instead of refactoring
+    // ---- hand-over between the two solve kernels (ssqp_wave.hip -> ssqp_kernels.hip) ----
+    // The wavefront kernel leaves a QP it cannot finish (free set or shape outside its limits) with its current
+    // (z, S) written to P.z / P.S, the passes done so far in fbIter[prob] and the problem id appended to fbList;
+    // the workgroup kernel then continues those QPs from exactly that state: the loop has no other state
+    // (SSQP.jl:237-377 recomputes everything from (z, S) in every pass).
+    unsigned int *fbCount;   // number of entries of fbList (device counter, zeroed before the launch)
+    int *fbList;             // problem ids handed over
+    long long *fbIter;       // per problem: loop passes already done
+    int resume;              // workgroup kernel: 1 = take the QPs of fbList (start from P.z, fbIter) instead of 0..nprob-1
+    double *wscratch;        // wavefront kernel: per-wavefront global scratch
+    size_t wscratchStride;   // doubles per wavefront
+    int waveLdsBytes;        // wavefront kernel: dynamic LDS per wavefront
+    int waveRC;              // wavefront kernel: row capacity of the kept factor
 };
 
 // Offsets of the LDS carve-up.  Double-typed regions first (offsets in
@@ -122,6 +135,16 @@ void launch_prep(int nct, int nrhs, int N, int M, int J, const double *A, const 
                  hipStream_t stream);
 hipError_t launch_genV(int nprob, int N, int T, double delta, unsigned long long seed0, double *V, hipStream_t stream);
 hipError_t launch_solve(const SolveParams &P, int grid, size_t ldsBytes, int wgPerCU, hipStream_t stream);
+
+// ---- wavefront kernel (ssqp_wave.hip): one 64-lane wavefront per QP ----
+constexpr int WAVE_MAXN = 512;   // dense N-vectors live in registers: 8 doubles per lane
+constexpr int WAVE_MJ = 11;      // constraint rows carried per free variable (M + J <= 11)
+bool wave_kernel_applies(int N, int M, int J);
+// LDS bytes one wavefront needs for a kept factor of `rc` rows (rc <= 127)
+int wave_lds_bytes(int rc);
+// doubles of global scratch per wavefront
+size_t wave_scratch_doubles(int N, int M, int J);
+hipError_t launch_solve_wave(const SolveParams &P, int grid, hipStream_t stream);
 
 }  // namespace ssqp
 #endif

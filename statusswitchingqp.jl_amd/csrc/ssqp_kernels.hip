@@ -32,30 +32,10 @@
 
 #include "ssqp_hip.h"
 #include "ssqp_internal.h"
+#include "ssqp_device.h"
 
 namespace ssqp {
 
-// orders the LDS/global accesses of the lanes of ONE wavefront (the wave runs in
-// lockstep; this only stops the compiler from moving accesses across it and
-// waits for outstanding ones)
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-}
-// 1/d by v_rcp_f64 and two Newton steps (about 1 ulp; the IEEE division sequence is ~3x longer and sits on
-// the critical path of every elimination step)
-__device__ __forceinline__ double fast_rcp(double d) {
-    double r = __builtin_amdgcn_rcp(d);
-    r = fma(fma(-d, r, 1.0), r, r);
-    r = fma(fma(-d, r, 1.0), r, r);
-    return r;
-}
-// x - d*y and x/d with the reference's two roundings (no FMA contraction)
-__device__ __forceinline__ double sub_mul_nc(double x, double d, double y) {
-#pragma clang fp contract(off)
-    const double t = d * y;
-    return x - t;
-}
 
 // ---- diagnostic build only (-DSSQP_PHASE_PROFILE): cycles per phase, thread 0 of each workgroup ----
 #ifdef SSQP_PHASE_PROFILE
@@ -98,155 +78,6 @@ __device__ unsigned long long g_phase[1024 * 32];
 #define SUBPHASE_DECL(t0) do { } while (0)
 #endif
 
-// ---------------------------------------------------------------- reductions
-// Wavefront reductions on DPP (data-parallel primitives: lane permutes inside the VALU, no LDS round
-// trip): xor-1 and xor-2 by quad_perm, then row_half_mirror and row_mirror complete a 16-lane row; the two
-// cross-row steps use the 64-lane shuffle.  Every lane ends with the result.  All 64 lanes must be active.
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-    // (every lane is written by these in-row permutes: no `old` operand, so no copy in front of the v_mov_dpp)
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int v) {
-    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, false);
-}
-// v_max_f64 / v_min_f64 as single instructions: fmax()/fmin() put a canonicalising v_max(x, x) in front of every
-// operand (signalling-NaN semantics), which doubles the length of the reduction chains.  Operands here are
-// never NaN by construction (|x|, ratios already filtered, +-inf sentinels).
-__device__ __forceinline__ double max_raw(double a, double b) {
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ double min_raw(double a, double b) {
-    double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
-constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
-constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7-i inside each 8 lanes
-constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15-i inside each 16 lanes
-
-// cross-row steps of a 64-lane reduction without the LDS: row_bcast15 (into rows 1 and 3) and row_bcast31 (into
-// rows 2 and 3) leave the result in lane 63; v_readlane hands it to every lane as a wavefront-uniform value
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ double dpp_f64_rows(double v, double oldv) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(__double2loint(oldv), lo, CTRL, ROWMASK, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(__double2hiint(oldv), hi, CTRL, ROWMASK, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double bcast63_f64(double v) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_sum(double v) {
-    v += dpp_f64<DPP_XOR1>(v);
-    v += dpp_f64<DPP_XOR2>(v);
-    v += dpp_f64<DPP_HALF_MIRROR>(v);
-    v += dpp_f64<DPP_MIRROR>(v);
-    v += dpp_f64_rows<0x142, 0xA>(v, 0.0);   // rows 1,3 += row 0,2 totals (other rows add 0)
-    v += dpp_f64_rows<0x143, 0xC>(v, 0.0);   // rows 2,3 += total of rows 0-1
-    return bcast63_f64(v);
-}
-__device__ __forceinline__ double wave_max(double v) {
-    v = max_raw(v, dpp_f64<DPP_XOR1>(v));
-    v = max_raw(v, dpp_f64<DPP_XOR2>(v));
-    v = max_raw(v, dpp_f64<DPP_HALF_MIRROR>(v));
-    v = max_raw(v, dpp_f64<DPP_MIRROR>(v));
-    v = max_raw(v, dpp_f64_rows<0x142, 0xA>(v, v));
-    v = max_raw(v, dpp_f64_rows<0x143, 0xC>(v, v));
-    return bcast63_f64(v);
-}
-
-// maximum over lanes 0..15 only (a 16-lane DPP row: four steps, no cross-row traffic), as a uniform value
-__device__ __forceinline__ double row0_max(double v) {
-    v = max_raw(v, dpp_f64<DPP_XOR1>(v));
-    v = max_raw(v, dpp_f64<DPP_XOR2>(v));
-    v = max_raw(v, dpp_f64<DPP_HALF_MIRROR>(v));
-    v = max_raw(v, dpp_f64<DPP_MIRROR>(v));
-    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double readlane_f64(double v, int srcLane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double wave_max_uniform(double v) { return wave_max(v); }
-// A value every lane holds identically (read from one LDS address, say) but the compiler cannot prove uniform:
-// pin it to scalar registers, so that everything derived from it (loop bounds, branches, addresses) runs on the
-// scalar unit instead of as per-lane arithmetic under exec masks.
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ double uni(double v) {
-    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-
-
-struct KeyMin {  // minimum value, ties -> smallest order
-    double v;
-    int ord;
-};
-__device__ __forceinline__ KeyMin keymin(KeyMin a, KeyMin b) {
-    const bool take = (b.v < a.v) | ((b.v == a.v) & (b.ord < a.ord));  // (no short circuit: straight-line code)
-    return KeyMin{take ? b.v : a.v, take ? b.ord : a.ord};
-}
-template <int CTRL>
-__device__ __forceinline__ KeyMin keymin_dpp(KeyMin a) {
-    KeyMin b;
-    b.v = dpp_f64<CTRL>(a.v);
-    b.ord = dpp_i32<CTRL>(a.ord);
-    return keymin(a, b);
-}
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ KeyMin keymin_rows(KeyMin a) {
-    KeyMin b;
-    b.v = dpp_f64_rows<CTRL, ROWMASK>(a.v, a.v);
-    b.ord = __builtin_amdgcn_update_dpp(a.ord, a.ord, CTRL, ROWMASK, 0xF, false);
-    return keymin(a, b);
-}
-__device__ __forceinline__ double wave_min(double v) {
-    v = min_raw(v, dpp_f64<DPP_XOR1>(v));
-    v = min_raw(v, dpp_f64<DPP_XOR2>(v));
-    v = min_raw(v, dpp_f64<DPP_HALF_MIRROR>(v));
-    v = min_raw(v, dpp_f64<DPP_MIRROR>(v));
-    v = min_raw(v, dpp_f64_rows<0x142, 0xA>(v, v));
-    v = min_raw(v, dpp_f64_rows<0x143, 0xC>(v, v));
-    return bcast63_f64(v);
-}
-// Two steps instead of a (value, order) pair through every reduction stage: the minimum value first, then the
-// smallest order among the lanes that hold it (one lane unless values tie exactly).  Values must not be NaN.
-__device__ __forceinline__ KeyMin wave_keymin(KeyMin a) {
-    KeyMin r;
-    r.v = wave_min(a.v);
-    const bool mine = (a.v == r.v);
-    unsigned long long tie = __ballot(mine);
-    int o = __builtin_amdgcn_readlane(a.ord, __ffsll((long long)tie) - 1);
-    tie &= tie - 1;
-    if (tie) {  // exact ties (or a wavefront without any candidate, all at +inf): integer minimum over the tied lanes
-        int q = mine ? a.ord : 0x7fffffff;
-        q = min(q, dpp_i32<DPP_XOR1>(q));
-        q = min(q, dpp_i32<DPP_XOR2>(q));
-        q = min(q, dpp_i32<DPP_HALF_MIRROR>(q));
-        q = min(q, dpp_i32<DPP_MIRROR>(q));
-        q = min(q, __builtin_amdgcn_update_dpp(q, q, 0x142, 0xA, 0xF, false));
-        q = min(q, __builtin_amdgcn_update_dpp(q, q, 0x143, 0xC, 0xF, false));
-        o = __builtin_amdgcn_readlane(q, 63);
-    }
-    r.ord = o;
-    return r;
-}
 
 struct Lds {
     double *z, *zm, *gam, *arena;
@@ -1690,58 +1521,6 @@ __device__ __forceinline__ int hb_partial(const double *__restrict__ V, int N, c
     return seen;
 }
 
-// lambda of the Schur system H lam = s (W <= WM <= 11), H symmetric (lower part given), one wavefront:
-// lane i holds row i of H and s_i; eliminations broadcast the pivot row with v_readlane.  The unit-lower factor
-// is also written to `tr` (WM*WM doubles of LDS scratch) column by column, so that the back substitution reads
-// column c of L into lane c and needs one broadcast per step instead of one per entry.  Returns false when a
-// pivot is not > 0 (the reference's cholesky(C) throws).  On return lane w < W holds lam_w.
-template <int WM>
-__device__ __forceinline__ bool small_spd_solve(const double *H, const double *rhs_, int W, double &lam, double *tr) {
-    const int lane = threadIdx.x & 63;
-    double a[WM];
-#pragma unroll
-    for (int c = 0; c < WM; ++c) {
-        const int r = lane < W ? lane : 0, cc = c < W ? c : 0;
-        const double v = (r >= cc) ? H[r + W * cc] : H[cc + W * r];  // symmetric read from the lower part
-        a[c] = (lane < W && c < W) ? v : 0.0;
-    }
-    double y = (lane < W) ? rhs_[lane] : 0.0;
-    bool ok = true;
-#pragma unroll
-    for (int c = 0; c < WM; ++c) {
-        if (c < W) {  // uniform
-            const double d = readlane_f64(a[c], c);
-            if (!(d > 0.0)) ok = false;
-            const double r = fast_rcp(d);
-            const double yc = readlane_f64(y, c);
-            const double lic = a[c] * r;  // L(i,c) for this lane's row i
-            const bool below = lane > c;
-            y = below ? fma(-lic, yc, y) : ((lane == c) ? y * r : y);  // forward substitution rides along; D^-1 on row c
-#pragma unroll
-            for (int c2 = 0; c2 < WM; ++c2) {  // (columns beyond W hold zeros: no guard on W)
-                if (c2 > c) {  // (rows <= c are finished and never read again: no predicate)
-                    const double bq = readlane_f64(a[c], c2);
-                    a[c2] = fma(-lic, bq, a[c2]);
-                }
-            }
-            if (below && lane < WM) tr[c * WM + lane] = lic;
-        }
-    }
-    wave_sync();
-    // y = D^-1 L^-1 s ; x = L'^-1 y with u[i] = L(i, lane)
-    double u[WM];
-#pragma unroll
-    for (int i = 1; i < WM; ++i) u[i] = tr[(lane < WM ? lane : 0) * WM + i];
-#pragma unroll
-    for (int i = WM - 1; i >= 1; --i) {
-        if (i < W) {  // uniform
-            const double xi = readlane_f64(y, i);
-            y = (lane < i) ? fma(-u[i], xi, y) : y;
-        }
-    }
-    lam = y;
-    return ok;
-}
 
 // zB[j] changed by dz (a variable entered B at a nonzero value, or left it): the cached hq = V[:,nz(zB)] zB + q and
 // bEall = rhs - [A;G] zB follow by ONE column each (hq += V[:,j] dz, bEall -= [A;G][:,j] dz) instead of being
@@ -2818,6 +2597,13 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
     C.garena = garena;
     C.iter = 0; C.ret = 0; C.det = SSQP_DETAIL_NONE;
     C.sBytes = 0; C.sRead = 0; C.sFlops = 0; C.sK3 = 0; C.maxK = 0; C.pathBits = 0;
+    // hand-over from the wavefront kernel (ssqp_wave.hip): continue from its (z, S) at its pass count
+    const double *zstart = P.x0 + (size_t)prob * N;
+    if (P.resume) {
+        C.iter = P.fbIter[prob];
+        zstart = P.z + (size_t)prob * N;
+        C.pathBits = 32;
+    }
     int32_t *Sg = P.S + (size_t)prob * (N + J);
     const double tol = P.tol;
 #ifdef SSQP_PHASE_PROFILE
@@ -2825,7 +2611,7 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
     C.ph_last = __builtin_amdgcn_s_memtime();
 #endif
 
-    for (int i = tid; i < N; i += NT) L.z[i] = P.x0[(size_t)prob * N + i];
+    for (int i = tid; i < N; i += NT) L.z[i] = zstart[i];
     for (int i = tid; i < N + J; i += NT) L.S[i] = Sg[i];
     for (int i = tid; i < N; i += NT) L.fpos[i] = -1;
     // incremental engine: arena = [scratch (X / AXPY staging / H) | Y | 1/d | factor], capacity RC rows
@@ -2995,6 +2781,15 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
             st.sum_k3 = C.sK3;
             st.max_k = C.maxK;
             st.path = C.pathBits;
+            if (P.resume) {  // add what the wavefront kernel counted before the hand-over
+                const ssqp_stats s0 = P.stats[prob];
+                st.alg_bytes += s0.alg_bytes;
+                st.read_bytes += s0.read_bytes;
+                st.alg_flops += s0.alg_flops;
+                st.sum_k3 += s0.sum_k3;
+                st.max_k = st.max_k > s0.max_k ? st.max_k : s0.max_k;
+                st.path |= s0.path;
+            }
             P.stats[prob] = st;
         }
     }
@@ -3057,9 +2852,14 @@ __global__ __launch_bounds__(NT, WPS) void ssqp_solve_kernel(SolveParams P) {
     for (;;) {
         if (threadIdx.x == 0) L.ired[2 * NW + 3] = (int)atomicAdd(P.queue, 1u);
         __syncthreads();
-        const int prob = L.ired[2 * NW + 3];
+        int prob = L.ired[2 * NW + 3];
         __syncthreads();
-        if (prob >= P.nprob) break;
+        if (P.resume) {  // the QPs the wavefront kernel handed over
+            if (prob >= (int)*P.fbCount) break;
+            prob = P.fbList[prob];
+        } else if (prob >= P.nprob) {
+            break;
+        }
         solve_one<VEC>(P, prob, L, garena);
     }
 }

@@ -1,0 +1,1576 @@
+// ssqp_wave.hip -- gfx950 (MI355X / CDNA4): the active-set loop with ONE 64-lane WAVEFRONT per QP.
+//
+// The headline workload (BASELINE.json: batches of N = 512 portfolio QPs) runs with small free sets (K = |F| is
+// ~19 on average, at most ~80) and at most 11 constraint rows: every pass of solveQP(Q,S,x0) (reference:
+// src/SSQP.jl:237-377) is a few thousand dependent scalar-ish operations, not a matrix problem.  A workgroup of
+// four wavefronts with a barrier between its ~20 phases (ssqp_kernels.hip) spends most of its time waiting; this
+// kernel gives every QP one wavefront instead:
+//   * no workgroup barrier anywhere -- all exchanges are DPP / v_readlane / ds_bpermute inside the wavefront;
+//   * four (or more) independent QPs per CU, one or two per SIMD, so every SIMD always has its own chain to run;
+//   * everything that belongs to a free variable lives in the REGISTERS of "its" lane (row r of the kept factor
+//     = lane r & 63 of slot r >> 6): z, bounds, its column of [A;G], the forward-substituted border rows Y;
+//   * N-vectors (hq = V[:,nz(zB)] zB + q, z, S, gamma) live in registers too, 8 doubles per lane (N <= 512);
+//   * LDS holds only the kept LDL' factor of V[F,F] and the 12 x 12 Schur block;
+//   * the Schur block H = [AE; c'] V_FF^-1 [AE' c] is kept across passes for ALL rows of [A;G]: an appended free
+//     variable adds one rank-1 term, a deleted one removes one (H -= g g'/m, the block-inverse identity), so a
+//     change of the active inequality set costs nothing and no pass re-forms H from the factor.
+// Pass structure and every decision rule (thresholds, tie rules, event order) are those of the reference, cited
+// line by line below; the arithmetic that only feeds threshold tests far above rounding noise (dot products,
+// factor + solve instead of explicit inverses) is free to use another order, as in ssqp_kernels.hip.
+//
+// Shapes this kernel takes: N even, N <= 512, M + J <= 11.  A QP whose free set outgrows the factor capacity is
+// HANDED OVER: its current (z, S) and pass count are written out and the workgroup kernel continues from exactly
+// that state (the loop has no other state: the reference recomputes everything from (z, S) in every pass).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ssqp_hip.h"
+#include "ssqp_internal.h"
+#include "ssqp_device.h"
+
+namespace ssqp {
+namespace wv {
+
+constexpr int MJX = WAVE_MJ;  // constraint rows carried (M + J <= MJX)
+constexpr int NR = MJX + 1;   // border columns: every row of [A;G] and c
+constexpr int CC = MJX;       // index of the c column
+constexpr int NCH = 4;        // dense layout: element i sits in lane (i >> 1) & 63, chunk i >> 7, half i & 1
+constexpr int KSLOT = 64;     // rows per register slot
+constexpr double INF = __builtin_huge_val();
+
+// compile-time loop: the body sees its index as a constant, so every register-array index is static whatever
+// the optimiser decides about unrolling
+template <int I>
+struct IC {
+    static constexpr int value = I;
+};
+template <int B, int E, class F>
+__device__ __forceinline__ void sfor(F &&f) {
+    if constexpr (B < E) {
+        f(IC<B>{});
+        sfor<B + 1, E>(f);
+    }
+}
+#define SFOR_BODY(name) [&](auto name##_c) __attribute__((always_inline))
+#define SFOR_IDX(name) constexpr int name = decltype(name##_c)::value
+
+// ------------------------------------------------------------------ lane helpers
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+template <int SL>
+__device__ __forceinline__ double rbcast(const double (&v)[2], int r) {  // value of row r (uniform r)
+    if (SL == 1) return readlane_f64(v[0], r);
+    const double a = readlane_f64(v[0], r & 63), b = readlane_f64(v[1], r & 63);
+    return (r < KSLOT) ? a : b;
+}
+template <int SL>
+__device__ __forceinline__ int rbcast_i(const int (&v)[2], int r) {
+    if (SL == 1) return __builtin_amdgcn_readlane(v[0], r);
+    const int a = __builtin_amdgcn_readlane(v[0], r & 63), b = __builtin_amdgcn_readlane(v[1], r & 63);
+    return (r < KSLOT) ? a : b;
+}
+template <int SL>
+__device__ __forceinline__ void set_row(double (&v)[2], int r, double x) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int t = 0; t < SL; ++t) v[t] = (lane + KSLOT * t == r) ? x : v[t];
+}
+template <int SL>
+__device__ __forceinline__ void set_row_i(int (&v)[2], int r, int x) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int t = 0; t < SL; ++t) v[t] = (lane + KSLOT * t == r) ? x : v[t];
+}
+// value held by lane `src` (per-lane src): LDS crossbar, no memory
+__device__ __forceinline__ int bperm_i(int v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
+__device__ __forceinline__ double bperm_f64(double v, int src) {
+    const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// rows p.. move up by one (row r takes row r+1) in a per-row register pair
+template <int SL>
+__device__ __forceinline__ void shift_up(double (&v)[2], int p) {
+    const int lane = lane_id();
+    const double n0 = bperm_f64(v[0], (lane + 1) & 63);
+    if (SL == 1) {
+        v[0] = (lane >= p) ? n0 : v[0];
+    } else {
+        const double n1 = bperm_f64(v[1], (lane + 1) & 63);
+        const double first1 = readlane_f64(v[1], 0);
+        const double m0 = (lane == 63) ? first1 : n0;
+        v[0] = (lane >= p) ? m0 : v[0];
+        v[1] = (lane + KSLOT >= p) ? n1 : v[1];
+    }
+}
+template <int SL>
+__device__ __forceinline__ void shift_up_i(int (&v)[2], int p) {
+    const int lane = lane_id();
+    const int n0 = bperm_i(v[0], (lane + 1) & 63);
+    if (SL == 1) {
+        v[0] = (lane >= p) ? n0 : v[0];
+    } else {
+        const int n1 = bperm_i(v[1], (lane + 1) & 63);
+        const int first1 = __builtin_amdgcn_readlane(v[1], 0);
+        const int m0 = (lane == 63) ? first1 : n0;
+        v[0] = (lane >= p) ? m0 : v[0];
+        v[1] = (lane + KSLOT >= p) ? n1 : v[1];
+    }
+}
+
+// ------------------------------------------------------------------ dense N-vectors in registers
+__device__ __forceinline__ int dk_of(int i) { return ((i >> 7) << 1) | (i & 1); }
+__device__ __forceinline__ int dl_of(int i) { return (i >> 1) & 63; }
+// element i (uniform) of a dense vector.  The lane's eight components are broadcast first and the choice is made
+// among the broadcast values: a select chain over the components themselves is folded by the optimiser into ONE
+// load at a computed offset, and a computed offset into the state keeps the whole state out of registers.
+__device__ __forceinline__ double dense_get(const double2 (&v)[NCH], int i) {
+    const int k = dk_of(i), l = dl_of(i);
+    double x = readlane_f64(v[0].x, l);
+    const double c1 = readlane_f64(v[0].y, l), c2 = readlane_f64(v[1].x, l), c3 = readlane_f64(v[1].y, l);
+    const double c4 = readlane_f64(v[2].x, l), c5 = readlane_f64(v[2].y, l), c6 = readlane_f64(v[3].x, l);
+    const double c7 = readlane_f64(v[3].y, l);
+    x = (k == 1) ? c1 : x;
+    x = (k == 2) ? c2 : x;
+    x = (k == 3) ? c3 : x;
+    x = (k == 4) ? c4 : x;
+    x = (k == 5) ? c5 : x;
+    x = (k == 6) ? c6 : x;
+    x = (k == 7) ? c7 : x;
+    return x;
+}
+__device__ __forceinline__ void dense_set(double2 (&v)[NCH], int i, double x) {  // uniform i
+    const int k = dk_of(i);
+    const bool me = lane_id() == dl_of(i);
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        v[m].x = (me && k == 2 * m) ? x : v[m].x;
+        v[m].y = (me && k == 2 * m + 1) ? x : v[m].y;
+    }
+}
+// per-lane index: v[idx] for every lane (row lanes fetching their variable's entry)
+__device__ __forceinline__ double dense_gather(const double2 (&v)[NCH], int idx) {
+    const int k = dk_of(idx), l = dl_of(idx);
+    double r = 0.0;
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        const double a = bperm_f64(v[m].x, l), b = bperm_f64(v[m].y, l);
+        r = (k == 2 * m) ? a : r;
+        r = (k == 2 * m + 1) ? b : r;
+    }
+    return r;
+}
+__device__ __forceinline__ int st_get(unsigned Sp, int i) {  // status of variable i (uniform i)
+    return (int)((unsigned)__builtin_amdgcn_readlane((int)Sp, dl_of(i)) >> (4 * dk_of(i))) & 15;
+}
+__device__ __forceinline__ void st_set(unsigned &Sp, int i, int s) {
+    const int sh = 4 * dk_of(i);
+    if (lane_id() == dl_of(i)) Sp = (Sp & ~(15u << sh)) | ((unsigned)s << sh);
+}
+__device__ __forceinline__ int st_of(unsigned Sp, int k) { return (int)(Sp >> (4 * k)) & 15; }
+
+// acc += w * column, column = N contiguous doubles (a column of V, a row of Ct, q); N even
+__device__ __forceinline__ void axpy_dense(double2 (&acc)[NCH], const double *__restrict__ col, double w, int N) {
+    const int lane = lane_id();
+    double2 v[NCH];
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        const int r = 2 * lane + 128 * m;
+        v[m] = *reinterpret_cast<const double2 *>(col + (r < N ? r : 0));
+    }
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        const int r = 2 * lane + 128 * m;
+        const double wk = (r < N) ? w : 0.0;
+        acc[m].x = fma(v[m].x, wk, acc[m].x);
+        acc[m].y = fma(v[m].y, wk, acc[m].y);
+    }
+}
+
+// ------------------------------------------------------------------ state
+struct Fac {
+    double *L0;  // rows and columns < 64: packed columns, column c holds rows c..63 at cofs64(c) (slot c unused)
+    double *L1;  // rows >= 64: element (r, c) at c * R1 + (r - 64)
+    int R1;
+};
+__device__ __forceinline__ int cofs64(int c) { return c * 64 - ((c * (c - 1)) >> 1); }
+
+struct Rows {  // one entry per row of the kept factor = per free variable, row r in lane r & 63 of slot r >> 6
+    int ord[2], rank[2];         // variable index; its rank among the free variables by index (findall order)
+    double zF[2], ur[2], dr[2];  // z, upper and lower bound of the variable
+    double dg[2], rd[2];         // pivot d_r of the LDL' factor and its reciprocal
+    double cF[2];                // c_r = hq[ord_r]  (SSQP.jl:324)
+    double X[MJX][2];            // column ord_r of [A;G]: X[w] = [A;G][w, ord_r]
+    double Y[NR][2];             // forward-substituted border: Y[w] = (L^-1 [A;G][w,F]')_r, Y[CC] = (L^-1 c)_r
+};
+
+struct WLds {
+    Fac F;
+    double *H;      // NR x NR, symmetric, full: H[a][b] = sum_r Y[a]_r Y[b]_r / d_r
+    double *Hs;     // W x W gathered block for the lambda solve
+    double *tr;     // scratch of small_spd_solve
+    double *tv;     // right-hand side of the lambda solve
+    double *aLrow;  // alphaL by row id
+    double *yn;     // 16 doubles: a new border row / the downdate vector
+    int16_t *ra;    // kept row ids in order
+};
+
+// one column of the factor for this lane's rows, zero where there is no entry (rows <= c, rows >= K, !valid)
+template <int SL>
+__device__ __forceinline__ void load_col(const Fac &F, int K, int c, double (&l)[2]) {
+    const int lane = lane_id();
+    const bool valid = c < K;
+    const int cc = valid ? c : 0;
+    {
+        const int c0 = cc < 63 ? cc : 63;
+        const double v = F.L0[cofs64(c0) - c0 + (lane > c0 ? lane : c0)];
+        l[0] = (valid && lane > cc && lane < K) ? v : 0.0;
+    }
+    if (SL == 2) {
+        const int rl = lane < F.R1 ? lane : F.R1 - 1;
+        const double v = F.L1[cc * F.R1 + rl];
+        l[1] = (valid && KSLOT + lane > cc && KSLOT + lane < K) ? v : 0.0;
+    } else {
+        l[1] = 0.0;
+    }
+}
+template <int SL>
+__device__ __forceinline__ void load_cols4(const Fac &F, int K, int c0, double (&l)[4][2]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load_col<SL>(F, K, c0 + u, l[u]);
+}
+// element (r, c), r > c, per-lane r (r may be in either part when SL == 2), uniform c
+template <int SL>
+__device__ __forceinline__ double fac_get(const Fac &F, int r, int c) {
+    const int c0 = c < 63 ? c : 63;
+    const int r0 = r < 64 ? (r > c0 ? r : c0) : 63;
+    const double a = F.L0[cofs64(c0) - c0 + r0];
+    if (SL == 1) return a;
+    int r1 = r >= 64 ? r - 64 : 0;
+    r1 = r1 < F.R1 ? r1 : F.R1 - 1;
+    const double b = F.L1[c * F.R1 + r1];
+    return (r < 64) ? a : b;
+}
+template <int SL>
+__device__ __forceinline__ void fac_put(const Fac &F, int r, int c, double v, bool on) {
+    if (SL == 1) {
+        if (on) F.L0[cofs64(c) - c + r] = v;
+    } else {
+        if (on && r < 64) F.L0[cofs64(c) - c + r] = v;
+        if (on && r >= 64) F.L1[c * F.R1 + (r - 64)] = v;
+    }
+}
+
+// ------------------------------------------------------------------ kept factor: append / delete
+// Append variable j as row K (SSQP.jl:322 refactors V[F,F] from scratch; here one forward substitution).
+// lnew = the new row of L (for the border update).  Returns the new pivot (must be > 0).
+template <int SL>
+__device__ __forceinline__ double append_row(const Fac &F, Rows &R, int K, int j, const double *__restrict__ V, int N,
+                                             double (&lnew)[2]) {
+    const int lane = lane_id();
+    const double *__restrict__ col = V + (size_t)j * N;
+    const double vjj = col[j];
+    double y[2] = {0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int r = lane + KSLOT * t;
+        const double v = col[r < K ? R.ord[t] : j];
+        y[t] = (r < K) ? v : 0.0;
+    }
+    {
+        double lc[4][2], ln[4][2];
+        load_cols4<SL>(F, K, 0, lc);
+        for (int c0 = 0; c0 < K; c0 += 4) {
+            load_cols4<SL>(F, K, c0 + 4, ln);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (c0 + u < K) {  // uniform
+                    const double yc = rbcast<SL>(y, c0 + u);
+#pragma unroll
+                    for (int t = 0; t < SL; ++t) y[t] = fma(-lc[u][t], yc, y[t]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < SL; ++t) lc[u][t] = ln[u][t];
+        }
+    }
+    double part = 0.0;
+    lnew[0] = lnew[1] = 0.0;
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int r = lane + KSLOT * t;
+        const double tr = (r < K) ? y[t] * R.rd[t] : 0.0;
+        part = fma(y[t], tr, part);
+        lnew[t] = tr;
+        if (K < 64) {
+            if (t == 0 && r < K) F.L0[cofs64(r) - r + K] = tr;
+        } else if (SL == 2) {
+            if (r < K) F.L1[r * F.R1 + (K - 64)] = tr;
+        }
+    }
+    const double dnew = vjj - wave_sum(part);
+    wave_sync();
+    return dnew;
+}
+
+// Delete row p: L33 D3 L33' += d_p l l' on the trailing block (rank-1 update, one column per step), then the
+// row/column is removed from the packed storage.  pv receives p_k = (L33^-1 l)_k in row k (the downdate of H
+// and nothing else needs it); dg/rd of the rows > p are updated in place (still in their OLD positions).
+template <int SL>
+__device__ __forceinline__ void delete_update(const Fac &F, Rows &R, int K, int p, double (&pv)[2]) {
+    const int lane = lane_id();
+    double w[2];
+    load_col<SL>(F, K, p, w);
+    pv[0] = pv[1] = 0.0;
+    double alpha = rbcast<SL>(R.dg, p);
+    double lc[2], ln[2];
+    load_col<SL>(F, K, p + 1, lc);
+    for (int k = p + 1; k < K; ++k) {
+        load_col<SL>(F, K, k + 1, ln);
+        const double pk = rbcast<SL>(w, k);
+        const double dk = rbcast<SL>(R.dg, k);
+        const double dn = fma(alpha * pk, pk, dk);
+        const double rdn = fast_rcp(dn);
+        const double beta = pk * alpha * rdn;
+        alpha = alpha * dk * rdn;
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + KSLOT * t;
+            if (r == k) {
+                R.dg[t] = dn;
+                R.rd[t] = rdn;
+                pv[t] = pk;
+            }
+            const bool below = r > k && r < K;
+            w[t] = below ? fma(-pk, lc[t], w[t]) : w[t];
+            fac_put<SL>(F, r, k, fma(beta, w[t], lc[t]), below);
+        }
+#pragma unroll
+        for (int t = 0; t < SL; ++t) lc[t] = ln[t];
+    }
+    wave_sync();
+}
+template <int SL>
+__device__ __forceinline__ void delete_compact(const Fac &F, int K, int p) {
+    const int lane = lane_id();
+    for (int c = 0; c < p; ++c) {  // columns c < p lose row p: rows r > p move up by one inside the column
+        double a[2];
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int rn = lane + KSLOT * t;  // new row
+            a[t] = (rn >= p && rn + 1 < K) ? fac_get<SL>(F, rn + 1, c) : 0.0;
+        }
+        wave_sync();
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int rn = lane + KSLOT * t;
+            fac_put<SL>(F, rn, c, a[t], rn >= p && rn + 1 < K);
+        }
+    }
+    for (int c = p + 1; c < K; ++c) {  // column c -> c - 1, rows r > c -> r - 1 (ascending: the target is vacated)
+        double a[2];
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int rn = lane + KSLOT * t;
+            a[t] = (rn >= c && rn + 1 < K) ? fac_get<SL>(F, rn + 1, c) : 0.0;
+        }
+        wave_sync();
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int rn = lane + KSLOT * t;
+            fac_put<SL>(F, rn, c - 1, a[t], rn >= c && rn + 1 < K);
+        }
+    }
+    wave_sync();
+}
+
+// forward substitution L y = b of the border columns selected by `cols` (bit w), from their raw right-hand sides
+template <int SL>
+__device__ __forceinline__ void border_sweep(const Fac &F, Rows &R, int K, unsigned cols) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int w = 0; w < NR; ++w) {
+        if ((cols >> w) & 1u) {  // uniform
+#pragma unroll
+            for (int t = 0; t < SL; ++t) {
+                const int r = lane + KSLOT * t;
+                const double raw = (w == CC) ? R.cF[t] : R.X[w < MJX ? w : 0][t];
+                R.Y[w][t] = (r < K) ? raw : 0.0;
+            }
+        }
+    }
+    double lc[4][2], ln[4][2];
+    load_cols4<SL>(F, K, 0, lc);
+    for (int c0 = 0; c0 < K; c0 += 4) {
+        load_cols4<SL>(F, K, c0 + 4, ln);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (c0 + u < K) {  // uniform
+#pragma unroll
+                for (int w = 0; w < NR; ++w) {
+                    if ((cols >> w) & 1u) {
+                        const double yc = rbcast<SL>(R.Y[w], c0 + u);
+#pragma unroll
+                        for (int t = 0; t < SL; ++t) R.Y[w][t] = fma(-lc[u][t], yc, R.Y[w][t]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < SL; ++t) lc[u][t] = ln[u][t];
+    }
+}
+
+// back substitution L' x = v (unit upper), v in the row registers
+// L(r, c) for uniform r and c = this lane's row index (a gathered row of the factor); 0 where c >= r
+template <int SL>
+__device__ __forceinline__ void load_rowT(const Fac &F, int r, double (&l)[2]) {
+    const int lane = lane_id();
+    l[0] = l[1] = 0.0;
+    if (r <= 0) return;  // uniform
+    if (r < 64) {
+        const bool live = lane < r;
+        const double x = F.L0[live ? cofs64(lane) - lane + r : 0];
+        l[0] = live ? x : 0.0;
+    } else if (SL == 2) {
+        const double a = F.L1[lane * F.R1 + (r - 64)];  // columns 0..63 all lie left of row r
+        l[0] = a;
+        const bool live = KSLOT + lane < r;
+        const double b = F.L1[(live ? KSLOT + lane : 0) * F.R1 + (r - 64)];
+        l[1] = live ? b : 0.0;
+    }
+}
+template <int SL>
+__device__ __forceinline__ void back_sweep(const Fac &F, int K, double (&v)[2]) {
+    double lc[4][2], ln[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load_rowT<SL>(F, K - 1 - u, lc[u]);
+    for (int r0 = K - 1; r0 > 0; r0 -= 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load_rowT<SL>(F, r0 - 4 - u, ln[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (r0 - u > 0) {  // uniform
+                const double xr = rbcast<SL>(v, r0 - u);
+#pragma unroll
+                for (int t = 0; t < SL; ++t) v[t] = fma(-lc[u][t], xr, v[t]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) lc[u][t] = ln[u][t];
+    }
+}
+
+// ------------------------------------------------------------------ getRowsGJr (utils.jl:49-86) in registers
+// X = [AE bE]: lanes own the columns (free variable r -> lane r & 63 of slot r >> 6, the right-hand side is
+// column K), the rows are the ACTIVE rows of [A;G] in increasing row id -- the row loop is unrolled over the row
+// ids, inactive ones are skipped by a uniform branch, so every register index is static.  The reference's column
+// permutation c0 is a position per column: initially the variable's rank among the free variables (findall
+// order), K for the right-hand side; the pivot is the FIRST maximum of |X[i, c0[j:nc]]| in c0 order.  Arithmetic
+// as in the reference, operation for operation (IEEE division, multiply and subtract rounded separately).
+// Returns the kept rows as a bit mask over row ids.
+template <int CS>
+__device__ __forceinline__ unsigned rank_filter(const Rows &R, double bEv, unsigned act, int K, double tol) {
+    const int lane = lane_id();
+    const int nc = K + 1;
+    double x[MJX][CS];
+    int posn[CS];
+    sfor<0, CS>(SFOR_BODY(cs) {
+        SFOR_IDX(cs);
+        const int t = lane + KSLOT * cs;
+        posn[cs] = (t < K) ? R.rank[cs] : ((t == K) ? K : 0x7fff0000);
+        sfor<0, MJX>(SFOR_BODY(i) {
+            SFOR_IDX(i);
+            const double be = readlane_f64(bEv, i);
+            x[i][cs] = (t < K) ? R.X[i][cs] : ((t == K) ? be : 0.0);
+        });
+    });
+    unsigned kept = 0;
+    int j = 0;
+    sfor<0, MJX>(SFOR_BODY(i) {
+        SFOR_IDX(i);
+        if (((act >> i) & 1u) && j < nc) {  // uniform
+            double am = -1.0;
+            int ap = 0x7fffffff;
+            sfor<0, CS>(SFOR_BODY(cs) {
+                SFOR_IDX(cs);
+                const bool in = (posn[cs] >= j) & (posn[cs] < nc);
+                const double a = in ? fabs(x[i][cs]) : -1.0;
+                const bool better = (a > am) | ((a == am) & (posn[cs] < ap));
+                am = better ? a : am;
+                ap = better ? posn[cs] : ap;
+            });
+            const double m = wave_max(am);
+            if (m > tol) {  // utils.jl:61 (uniform)
+                unsigned long long tie = __ballot(am == m);
+                int mlane = __ffsll((long long)tie) - 1;
+                int mpos = __builtin_amdgcn_readlane(ap, mlane);
+                tie &= tie - 1;
+                while (tie) {
+                    const int l2 = __ffsll((long long)tie) - 1;
+                    const int p2 = __builtin_amdgcn_readlane(ap, l2);
+                    mlane = p2 < mpos ? l2 : mlane;
+                    mpos = p2 < mpos ? p2 : mpos;
+                    tie &= tie - 1;
+                }
+                kept |= 1u << i;
+                // c0[mj] <-> c0[j]; the pivot column broadcasts its entries of this row and the active rows below
+                double dcol[MJX];
+                sfor<0, MJX>(SFOR_BODY(k) {
+                    SFOR_IDX(k);
+                    dcol[k] = 0.0;
+                });
+                sfor<0, CS>(SFOR_BODY(cs) {
+                    SFOR_IDX(cs);
+                    const int pz = posn[cs];
+                    posn[cs] = (pz == mpos) ? j : ((pz == j) ? mpos : pz);
+                    const unsigned long long own = __ballot(posn[cs] == j);
+                    if (own) {  // uniform: the owner lane holds the pivot column in this slot
+                        const int src = __ffsll((long long)own) - 1;
+                        sfor<i, MJX>(SFOR_BODY(k) {
+                            SFOR_IDX(k);
+                            if ((act >> k) & 1u) dcol[k] = readlane_f64(x[k][cs], src);
+                        });
+                    }
+                });
+                sfor<0, CS>(SFOR_BODY(cs) {
+                    SFOR_IDX(cs);
+                    const double xn = x[i][cs] / dcol[i];  // utils.jl:68-70
+                    sfor<i + 1, MJX>(SFOR_BODY(k) {        // utils.jl:71-78 (rows above are never read again)
+                        SFOR_IDX(k);
+                        if ((act >> k) & 1u) x[k][cs] = sub_mul_nc(x[k][cs], dcol[k], xn);
+                    });
+                });
+                j += 1;
+            }
+        }
+    });
+    return kept;
+}
+
+// ------------------------------------------------------------------ Schur block
+// H[a][b] -= / += over all pairs, three entries per lane
+__device__ __forceinline__ void h_rank1(const WLds &L, double scale) {  // H += scale * yn yn'
+    const int lane = lane_id();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int e = lane + 64 * q;
+        if (e < NR * NR) {
+            const int a = e / NR, b = e - a * NR;
+            L.H[e] = fma(L.yn[a] * scale, L.yn[b], L.H[e]);
+        }
+    }
+}
+
+}  // namespace wv
+
+using namespace wv;
+
+// ====================================================================================================
+// one QP, one wavefront
+// ====================================================================================================
+struct WCtx {
+    int N, M, J, MJ;
+    double tol, tolG;
+    const double *__restrict__ V;
+    const double *__restrict__ Ct;
+    const double *__restrict__ rhs;
+    const double *__restrict__ q;
+    const double *__restrict__ dlo;
+    const double *__restrict__ uhi;
+    ssqp_trace *trace;
+    int ntrace;
+    int RC;
+    long long iter, ret;
+    int det;
+    long long sBytes, sRead, sFlops, sK3;
+    int maxK;
+};
+
+enum { W_CONTINUE = 0, W_BREAK = 1, W_HANDOVER = 2 };
+
+// every dense vector / status update that follows a change of z[j] of a BOUND variable by dz (it entered B at a
+// nonzero value, or leaves B): hq += V[:,j] dz, bEall -= [A;G][:,j] dz  (the caches of SSQP.jl:295,324)
+__device__ __forceinline__ void bound_shift(const WCtx &C, double2 (&hq)[NCH], double &bEv, int j, double dz) {
+    axpy_dense(hq, C.V + (size_t)j * C.N, dz, C.N);
+    const int lane = lane_id();
+    const double cj = C.Ct[(size_t)(lane < C.MJ ? lane : 0) * C.N + j];
+    bEv = (lane < C.MJ) ? fma(-cj, dz, bEv) : bEv;
+}
+
+template <int SL>
+__device__ __forceinline__ void recompute_H_c(const WLds &L, const Rows &R, int K, int MJ) {
+    // t = H[:, c]: H[a][c] = H[c][a] = sum_r Y[a]_r y_c,r / d_r for every row a of [A;G]
+    const int lane = lane_id();
+#pragma unroll
+    for (int a = 0; a < MJX; ++a) {
+        if (a < MJ) {  // uniform
+            double s = 0.0;
+#pragma unroll
+            for (int t = 0; t < SL; ++t) {
+                const int r = lane + KSLOT * t;
+                s = (r < K) ? fma(R.Y[a][t] * R.rd[t], R.Y[CC][t], s) : s;
+            }
+            s = wave_sum(s);
+            if (lane == 0) {
+                L.H[a * NR + CC] = s;
+                L.H[CC * NR + a] = s;
+            }
+        }
+    }
+    wave_sync();
+}
+template <int SL>
+__device__ __forceinline__ void recompute_H_all(const WLds &L, const Rows &R, int K, int MJ) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int a = 0; a < NR; ++a) {
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            if ((a < MJ || a == CC) && (b < MJ || b == CC)) {  // uniform
+                double s = 0.0;
+#pragma unroll
+                for (int t = 0; t < SL; ++t) {
+                    const int r = lane + KSLOT * t;
+                    s = (r < K) ? fma(R.Y[a][t] * R.rd[t], R.Y[b][t], s) : s;
+                }
+                s = wave_sum(s);
+                if (lane == 0) {
+                    L.H[a * NR + b] = s;
+                    L.H[b * NR + a] = s;
+                }
+            }
+        }
+    }
+    wave_sync();
+}
+
+// Append variable j: factor row, per-row registers, border row, Schur block.  Returns false when the new pivot is
+// not > 0 (cholesky(V[F,F]) of the reference throws, SSQP.jl:322).
+template <int SL>
+__device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int &K, int j, const double2 (&hq)[NCH],
+                                           const double2 (&zd)[NCH]) {
+    const int lane = lane_id();
+    const int N = C.N, MJ = C.MJ;
+    double lnew[2];
+    const double dnew = append_row<SL>(L.F, R, K, j, C.V, N, lnew);
+    if (!(dnew > 0.0)) return false;
+    const double rdn = fast_rcp(dnew);
+    // rank among the free variables by index: rows with a larger index move up by one
+    int below = 0;
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int r = lane + KSLOT * t;
+        const bool lt = (r < K) && (R.ord[t] < j);
+        below += __popcll(__ballot(lt));
+        R.rank[t] = ((r < K) && (R.ord[t] > j)) ? R.rank[t] + 1 : R.rank[t];
+    }
+    const double cj = C.Ct[(size_t)(lane < MJ ? lane : 0) * N + j];  // column j of [A;G], row w in lane w
+    const double uj = C.uhi[j], dj = C.dlo[j];
+    const double zj = dense_get(zd, j), hj = dense_get(hq, j);
+    set_row_i<SL>(R.ord, K, j);
+    set_row_i<SL>(R.rank, K, below);
+    set_row<SL>(R.zF, K, zj);
+    set_row<SL>(R.ur, K, uj);
+    set_row<SL>(R.dr, K, dj);
+    set_row<SL>(R.dg, K, dnew);
+    set_row<SL>(R.rd, K, rdn);
+    set_row<SL>(R.cF, K, hj);
+    // border row: y_K,w = x_w - sum_c L(K,c) y_c,w
+#pragma unroll
+    for (int w = 0; w < NR; ++w) {
+        if (w < MJ || w == CC) {  // uniform
+            const double xw = (w == CC) ? hj : readlane_f64(cj, w < MJX ? w : 0);
+            double s = 0.0;
+#pragma unroll
+            for (int t = 0; t < SL; ++t) s = (lane + KSLOT * t < K) ? fma(lnew[t], R.Y[w][t], s) : s;
+            s = wave_sum(s);
+            const double yk = xw - s;
+            if (w < MJX) set_row<SL>(R.X[w < MJX ? w : 0], K, xw);
+            set_row<SL>(R.Y[w], K, yk);
+            if (lane == 0) L.yn[w] = yk;
+        } else if (lane == 0) {
+            L.yn[w] = 0.0;
+        }
+    }
+    wave_sync();
+    h_rank1(L, rdn);
+    wave_sync();
+    C.sRead += 64ll * K + 64ll * MJ + 16;
+    K += 1;
+    return true;
+}
+
+// Delete row p (its variable left F).  single: the border rows and H are still those of the current factor, so
+// H follows by the block-inverse downdate; otherwise the caller re-forms H.
+template <int SL>
+__device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p, int MJ, bool downdate) {
+    const int lane = lane_id();
+    double pv[2], rdold[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) rdold[t] = R.rd[t];
+    delete_update<SL>(L.F, R, K, p, pv);
+    if (downdate) {
+        // H' = H - g g' / m,  g = [A;G c']' V_FF^-1 e_p = Y' D^-1 f,  m = (V_FF^-1)_pp = f' D^-1 f,
+        // f = L^-1 e_p: f_p = 1, f_r = -p_r below (p = L33^-1 l, the vector the rank-1 update walks through)
+        double fr[2], frd[2], msum = 0.0;
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + KSLOT * t;
+            fr[t] = (r == p) ? 1.0 : ((r > p && r < K) ? -pv[t] : 0.0);
+            frd[t] = fr[t] * rdold[t];
+            msum = fma(fr[t], frd[t], msum);
+        }
+        const double mpp = wave_sum(msum);
+#pragma unroll
+        for (int w = 0; w < NR; ++w) {
+            double s = 0.0;
+            if (w < MJ || w == CC) {  // uniform
+#pragma unroll
+                for (int t = 0; t < SL; ++t) s = fma(R.Y[w][t], frd[t], s);
+                s = wave_sum(s);
+            }
+            if (lane == 0) L.yn[w] = s;
+        }
+        wave_sync();
+        h_rank1(L, -1.0 / mpp);
+        wave_sync();
+    }
+    delete_compact<SL>(L.F, K, p);
+    // per-row registers: rows above p move up
+    const int rp = rbcast_i<SL>(R.rank, p);
+    shift_up_i<SL>(R.ord, p);
+    shift_up_i<SL>(R.rank, p);
+    shift_up<SL>(R.zF, p);
+    shift_up<SL>(R.ur, p);
+    shift_up<SL>(R.dr, p);
+    shift_up<SL>(R.dg, p);
+    shift_up<SL>(R.rd, p);
+    shift_up<SL>(R.cF, p);
+#pragma unroll
+    for (int w = 0; w < MJX; ++w)
+        if (w < MJ) shift_up<SL>(R.X[w], p);
+    K -= 1;
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int r = lane + KSLOT * t;
+        R.rank[t] = (r < K && R.rank[t] > rp) ? R.rank[t] - 1 : R.rank[t];
+    }
+}
+
+// hq = q + sum over the bound variables with z != 0 of V[:,i] z_i;  bEall = rhs - [A;G] zB   (SSQP.jl:295,324)
+__device__ __forceinline__ void refresh_caches(WCtx &C, double2 (&hq)[NCH], double &bEv, const double2 (&zd)[NCH],
+                                               unsigned Sp) {
+    const int lane = lane_id();
+    const int N = C.N, MJ = C.MJ;
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        const int r = 2 * lane + 128 * m;
+        hq[m] = (r < N) ? *reinterpret_cast<const double2 *>(C.q + r) : make_double2(0.0, 0.0);
+    }
+    // zB: z of the bound variables, 0 for the free ones
+    double2 zb[NCH];
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        const int r = 2 * lane + 128 * m;
+        zb[m].x = (r < N && st_of(Sp, 2 * m) != SSQP_IN) ? zd[m].x : 0.0;
+        zb[m].y = (r < N && st_of(Sp, 2 * m + 1) != SSQP_IN) ? zd[m].y : 0.0;
+    }
+    int ncol = 0;
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        unsigned long long mx = __ballot(zb[m].x != 0.0), my = __ballot(zb[m].y != 0.0);
+        unsigned long long any = mx | my;
+        while (any) {  // by increasing index
+            const int l = __ffsll((long long)any) - 1;
+            any &= any - 1;
+            if ((mx >> l) & 1ull) {
+                axpy_dense(hq, C.V + (size_t)(2 * l + 128 * m) * N, readlane_f64(zb[m].x, l), N);
+                ncol += 1;
+            }
+            if ((my >> l) & 1ull) {
+                axpy_dense(hq, C.V + (size_t)(2 * l + 128 * m + 1) * N, readlane_f64(zb[m].y, l), N);
+                ncol += 1;
+            }
+        }
+    }
+    double be = 0.0;
+    for (int w = 0; w < MJ; ++w) {
+        const double *__restrict__ row = C.Ct + (size_t)w * N;
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < NCH; ++m) {
+            const int r = 2 * lane + 128 * m;
+            const double2 v = *reinterpret_cast<const double2 *>(row + (r < N ? r : 0));
+            s = (r < N) ? fma(v.y, zb[m].y, fma(v.x, zb[m].x, s)) : s;
+        }
+        s = wave_sum(s);
+        const double b = C.rhs[w] - s;
+        be = (lane == w) ? b : be;
+    }
+    bEv = be;
+    C.sRead += 8ll * N * (ncol + MJ + 1);
+}
+
+template <int SL>
+__device__ __forceinline__ void regather_c(Rows &R, int K, const double2 (&hq)[NCH]) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int r = lane + KSLOT * t;
+        const double v = dense_gather(hq, (r < K) ? R.ord[t] : 0);
+        R.cF[t] = (r < K) ? v : 0.0;
+    }
+}
+
+// The per-QP state that lives across passes
+struct WState {
+    Rows R;
+    double2 hq[NCH], zd[NCH];
+    unsigned Sp;        // statuses of this lane's 8 variables, 4 bits each
+    unsigned Emask;     // active inequalities (bit j: S[N+j] == EO)
+    double bEv;         // lane w: bEall_w = rhs_w - ([A;G] zB)_w
+    int K;
+    bool hbValid, cDirty;
+    // pending changes of F decided by the last pass
+    unsigned long long del0, del1;  // rows to delete (slot 0 / slot 1 lanes)
+    int appJ;                       // variable to append, or -1
+    bool appAll;                    // append every variable with status IN that has no row (start, after freeK!)
+};
+
+// One pass for K > 0 with the kept factor in sync.  SSQP.jl:287-375.
+template <int SL>
+__device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, double *__restrict__ gscr) {
+    const int lane = lane_id();
+    const int N = C.N, M = C.M, J = C.J, MJ = C.MJ;
+    const double tol = C.tol, tolG = C.tolG;
+    Rows &R = S.R;
+    const int K = S.K;
+    ssqp_trace *trace = (C.trace && C.iter <= C.ntrace) ? C.trace + (C.iter - 1) : nullptr;
+
+    // ---- active rows (SSQP.jl:288-294): all equalities, then the inequalities with status EO
+    const unsigned act = ((1u << M) - 1u) | (S.Emask << M);
+    const int W0 = __popc(act);
+    // ---- rank filter on [AE bE]  (SSQP.jl:310-319)
+    unsigned kept = act;
+    if (W0 > 0) {
+        if (SL == 1) kept = rank_filter<1>(R, S.bEv, act, K, tol);
+        else kept = rank_filter<2>(R, S.bEv, act, K, tol);
+    }
+    const int W = __popc(kept);
+    // kept row ids in order; alphaL by row id
+    if (lane < MJX + 1) L.aLrow[lane] = 0.0;
+    {
+        const unsigned below = kept & ((1u << (lane & 31)) - 1u);
+        if (lane < MJX && ((kept >> lane) & 1u)) L.ra[__popc(below)] = (int16_t)lane;
+    }
+    wave_sync();
+    // ---- Schur system (AE V^-1 AE') lam = bE + AE V^-1 c ; alphaL = -lam  (SSQP.jl:325-328, 351)
+    if (W > 0) {
+        for (int e = lane; e < W * W; e += 64) {
+            const int a = e % W, b = e / W;
+            L.Hs[a + W * b] = L.H[(int)L.ra[a] * NR + (int)L.ra[b]];
+        }
+        {   // right-hand side bE + t, t = AE V^-1 c = H[:, c]
+            const int a = L.ra[lane < W ? lane : 0];
+            const double be = bperm_f64(S.bEv, a);
+            if (lane < W) L.tv[lane] = be + L.H[a * NR + CC];
+        }
+        wave_sync();
+        double lam = 0.0;
+        bool okH = true;
+        if (W > 8) okH = small_spd_solve<MJX>(L.Hs, L.tv, W, lam, L.tr);
+        else if (W > 4) okH = small_spd_solve<8>(L.Hs, L.tv, W, lam, L.tr);
+        else okH = small_spd_solve<4>(L.Hs, L.tv, W, lam, L.tr);
+        if (!okH) {  // cholesky(C) of the reference throws (SSQP.jl:328)
+            C.ret = -1;
+            C.det = SSQP_DETAIL_POSDEF_C;
+            return W_BREAK;
+        }
+        if (lane < W) L.aLrow[L.ra[lane]] = -lam;
+        wave_sync();
+    }
+    // ---- alpha = -V_FF^-1 (AE' alphaL + c):  v = D^-1 (Y_A alphaL + y_c), alpha = -L'^-1 v   (SSQP.jl:329-331)
+    double v[2] = {0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < SL; ++t) v[t] = R.Y[CC][t];
+#pragma unroll
+    for (int w = 0; w < MJX; ++w) {
+        if ((kept >> w) & 1u) {  // uniform
+            const double al = L.aLrow[w];
+#pragma unroll
+            for (int t = 0; t < SL; ++t) v[t] = fma(R.Y[w][t], al, v[t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int r = lane + KSLOT * t;
+        v[t] = (r < K) ? v[t] * R.rd[t] : 0.0;
+    }
+    back_sweep<SL>(L.F, K, v);
+    double alpha[2], p[2];
+    double pa = 0.0;
+    int pnan = 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) alpha[t] = p[t] = 0.0;
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int r = lane + KSLOT * t;
+        alpha[t] = -v[t];
+        p[t] = (r < K) ? alpha[t] - R.zF[t] : 0.0;  // SSQP.jl:332
+        if (p[t] != p[t]) pnan = 1;
+        pa = fmax(pa, fabs(p[t]));
+    }
+    const double pinf = wave_max(pa);
+    const bool anyNan = __ballot(pnan) != 0ull;
+
+    {   // per-pass accounting
+        const long long k = K, r = N - K, w = W;
+        C.sBytes += 8ll * (k * k + r * k) + 8ll * MJ * N + 48ll * N + 4ll * (N + J);
+        C.sFlops += k * k * k + 4 * k * k * w + 2 * k * k + 2 * r * k + 2ll * W0 * r + w * w * w;
+        C.sK3 += k * k * k;
+    }
+
+    if (pinf > tolG && !anyNan) {  // ------------------------ aStep!  SSQP.jl:61-134
+        double Lr[2];
+        double lmin = INF;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) Lr[t] = INF;
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + KSLOT * t;
+            if (r < K) {
+                const double tt = p[t], h = R.zF[t];
+                if (tt > tol && R.ur[t] < INF) Lr[t] = (R.ur[t] - h) / tt;         // :69-71
+                else if (tt < -tol && R.dr[t] > -INF) Lr[t] = (R.dr[t] - h) / tt;  // :73-75
+                lmin = fmin(lmin, Lr[t]);
+            }
+        }
+        // inactive inequalities: zo = g - G z, po = G[:,F] p  (:78-89); the bound part of G z is cached in bEall
+        double lin = INF;  // lane j: ratio of inequality j
+#pragma unroll
+        for (int w = 0; w < MJX; ++w) {
+            if (w >= M && w < MJ && !((S.Emask >> (w - M)) & 1u)) {  // uniform: inactive inequality w - M
+                double sz = 0.0, sp = 0.0;
+#pragma unroll
+                for (int t = 0; t < SL; ++t) {
+                    const int r = lane + KSLOT * t;
+                    sz = (r < K) ? fma(R.X[w][t], R.zF[t], sz) : sz;
+                    sp = (r < K) ? fma(R.X[w][t], p[t], sp) : sp;
+                }
+                sz = wave_sum(sz);
+                sp = wave_sum(sp);
+                const double zo = readlane_f64(S.bEv, w) - sz;
+                const double ratio = (sp > tol) ? zo / sp : INF;  // :85-86
+                lin = (lane == w - M) ? ratio : lin;
+            }
+        }
+        lmin = fmin(lmin, lin);
+        const double L1 = wave_min(lmin);
+        C.sFlops += 2ll * (J - __popc(S.Emask)) * (N + K);
+        if (L1 < 1.0) {  // blocked  (:98-127)
+            int firstId = 0x7fffffff;
+            unsigned long long dm[2] = {0ull, 0ull};
+            bool hit[2] = {false, false};
+#pragma unroll
+            for (int t = 0; t < SL; ++t) {
+                const int r = lane + KSLOT * t;
+                if (r < K) {
+                    double zn = R.zF[t] + L1 * p[t];  // :99
+                    if (Lr[t] < INF && !(Lr[t] - L1 > tol)) {  // :102-116
+                        const bool up = p[t] > tol;
+                        zn = up ? R.ur[t] : R.dr[t];
+                        hit[t] = true;
+                        firstId = min(firstId, R.ord[t] + 1);
+                    }
+                    R.zF[t] = zn;
+                }
+                dm[t] = __ballot(hit[t]);
+            }
+            const bool ihit = (lin < INF) && !(lin - L1 > tol);
+            const unsigned long long im = __ballot(ihit);
+            if (ihit) firstId = min(firstId, N + lane + 1);
+            S.Emask |= (unsigned)im;
+            // the switched variables: statuses, z of the bound set, and the caches hq / bEall follow
+#pragma unroll
+            for (int t = 0; t < SL; ++t) {
+                unsigned long long mm = dm[t];
+                while (mm) {  // by increasing row (any order gives the same set; hq is updated column by column)
+                    const int l = __ffsll((long long)mm) - 1;
+                    mm &= mm - 1;
+                    const int jv = __builtin_amdgcn_readlane(R.ord[t], l);
+                    const double pj = readlane_f64(p[t], l);
+                    const double zn = readlane_f64(R.zF[t], l);
+                    st_set(S.Sp, jv, (pj > tol) ? SSQP_UP : SSQP_DN);
+                    dense_set(S.zd, jv, zn);
+                    if (zn != 0.0) {
+                        bound_shift(C, S.hq, S.bEv, jv, zn);
+                        S.cDirty = true;
+                        C.sRead += 8ll * N + 64ll * MJ;
+                    }
+                }
+            }
+            S.del0 = dm[0];
+            S.del1 = dm[1];
+            if (trace) {
+                int f = firstId;
+                f = min(f, dpp_i32<DPP_XOR1>(f));
+                f = min(f, dpp_i32<DPP_XOR2>(f));
+                f = min(f, dpp_i32<DPP_HALF_MIRROR>(f));
+                f = min(f, dpp_i32<DPP_MIRROR>(f));
+                f = min(f, __builtin_amdgcn_update_dpp(f, f, 0x142, 0xA, 0xF, false));
+                f = min(f, __builtin_amdgcn_update_dpp(f, f, 0x143, 0xC, 0xF, false));
+                f = __builtin_amdgcn_readlane(f, 63);
+                if (lane == 0) *trace = ssqp_trace{K, W, 1, f};
+            }
+            return W_CONTINUE;
+        }
+        // full step: z[F] = alpha  (:130)
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + KSLOT * t;
+            R.zF[t] = (r < K) ? alpha[t] : R.zF[t];
+        }
+    }
+
+    // ---- multipliers: gamma = V[B,F] alpha + V[B,B] zB + q[B] + AB' alphaL  (SSQP.jl:352)
+    //      = hq + V[:,F] alpha + [A;G][kept,:]' alphaL on the bound variables
+    double2 gam[NCH];
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) gam[m] = S.hq[m];
+    {
+        constexpr int NB = 4;  // columns in flight
+        for (int r0 = 0; r0 < K; r0 += NB) {
+            const double *__restrict__ col[NB];
+            double wj[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                const int r = (r0 + c < K) ? r0 + c : r0;
+                col[c] = C.V + (size_t)rbcast_i<SL>(R.ord, r) * N;
+                wj[c] = (r0 + c < K) ? rbcast<SL>(alpha, r) : 0.0;
+            }
+            double2 vv[NCH][NB];
+#pragma unroll
+            for (int m = 0; m < NCH; ++m) {
+                const int rr = 2 * lane + 128 * m;
+#pragma unroll
+                for (int c = 0; c < NB; ++c) vv[m][c] = *reinterpret_cast<const double2 *>(col[c] + (rr < N ? rr : 0));
+            }
+#pragma unroll
+            for (int m = 0; m < NCH; ++m) {
+                const int rr = 2 * lane + 128 * m;
+                const double keep = (rr < N) ? 1.0 : 0.0;
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    const double wk = wj[c] * keep;
+                    gam[m].x = fma(vv[m][c].x, wk, gam[m].x);
+                    gam[m].y = fma(vv[m][c].y, wk, gam[m].y);
+                }
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < MJX; ++w)
+            if ((kept >> w) & 1u) axpy_dense(gam, C.Ct + (size_t)w * N, L.aLrow[w], N);
+        C.sRead += 8ll * N * (K + W);
+    }
+    {
+        const long long r = N - K;
+        C.sBytes += 8ll * r * r;
+        C.sFlops += 2ll * r * r + 2ll * r * K;
+    }
+
+    // ---- KKTchk!  SSQP.jl:136-188
+    KeyMin ev{INF, 0x7fffffff};
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = 2 * lane + 128 * m + e;
+            const double g = e ? gam[m].y : gam[m].x;
+            const int s = st_of(S.Sp, 2 * m + e);
+            if (i < N) {
+                if (s == SSQP_UP && g > tolG) ev = keymin(ev, KeyMin{-g, i});        // :141-143
+                else if (s == SSQP_DN && g < -tolG) ev = keymin(ev, KeyMin{g, i});  // :144-146
+            }
+        }
+    }
+    if (S.Emask != 0u) {  // multipliers of the active inequalities (:149-171)
+        if (kept == act) {  // every active row kept its own multiplier
+            if (lane >= M && lane < MJ && ((act >> lane) & 1u)) {
+                const double Lda = L.aLrow[lane];
+                if (Lda < -tolG) ev = keymin(ev, KeyMin{Lda, N + lane - M});
+            }
+        } else {
+            // purged rows: Lda = alphaL' * (AE' \ GE[j,F])  (:158-159): least squares by modified Gram-Schmidt (two
+            // passes) on the K x W matrix AE' in the wavefront's global scratch
+            double *Q = gscr, *Rm = Q + (size_t)K * W, *yv = Rm + W * W;
+            {
+                int wi = 0;
+#pragma unroll
+                for (int w = 0; w < MJX; ++w) {
+                    if ((kept >> w) & 1u) {
+#pragma unroll
+                        for (int t = 0; t < SL; ++t) {
+                            const int r = lane + KSLOT * t;
+                            if (r < K) Q[r + (size_t)K * wi] = R.X[w][t];
+                        }
+                        wi += 1;
+                    }
+                }
+            }
+            for (int e = lane; e < W * W; e += 64) Rm[e] = 0.0;
+            wave_sync();
+            for (int c = 0; c < W; ++c) {
+                for (int pass = 0; pass < 2; ++pass)
+                    for (int b2 = 0; b2 < c; ++b2) {
+                        double s = 0.0;
+                        for (int k = lane; k < K; k += 64) s = fma(Q[k + (size_t)K * b2], Q[k + (size_t)K * c], s);
+                        s = wave_sum(s);
+                        for (int k = lane; k < K; k += 64) Q[k + (size_t)K * c] = fma(-s, Q[k + (size_t)K * b2], Q[k + (size_t)K * c]);
+                        if (lane == 0) Rm[b2 + W * c] += s;
+                        wave_sync();
+                    }
+                double s = 0.0;
+                for (int k = lane; k < K; k += 64) s = fma(Q[k + (size_t)K * c], Q[k + (size_t)K * c], s);
+                s = sqrt(wave_sum(s));
+                if (lane == 0) Rm[c + W * c] = s;
+                const double rs = (s > 0.0) ? 1.0 / s : 0.0;
+                for (int k = lane; k < K; k += 64) Q[k + (size_t)K * c] *= rs;
+                wave_sync();
+            }
+#pragma unroll
+            for (int w = 0; w < MJX; ++w) {
+                if (w >= M && ((act >> w) & 1u)) {  // active inequality w - M (uniform)
+                    double Lda;
+                    if ((kept >> w) & 1u) {
+                        Lda = L.aLrow[w];
+                    } else {
+                        for (int c = 0; c < W; ++c) {  // yq = Q' gv
+                            double s = 0.0;
+#pragma unroll
+                            for (int t = 0; t < SL; ++t) {
+                                const int r = lane + KSLOT * t;
+                                if (r < K) s = fma(Q[r + (size_t)K * c], R.X[w][t], s);
+                            }
+                            s = wave_sum(s);
+                            if (lane == 0) yv[c] = s;
+                        }
+                        wave_sync();
+                        double s = 0.0;
+                        if (lane == 0) {  // x = R^-1 yq ; Lda = alphaL . x
+                            for (int c = W - 1; c >= 0; --c) {
+                                double sv = yv[c];
+                                for (int b2 = c + 1; b2 < W; ++b2) sv -= Rm[c + W * b2] * yv[b2];
+                                yv[c] = (Rm[c + W * c] > 0.0) ? sv / Rm[c + W * c] : 0.0;
+                            }
+                            for (int c = 0; c < W; ++c) s = fma(L.aLrow[L.ra[c]], yv[c], s);
+                        }
+                        Lda = readlane_f64(s, 0);
+                        wave_sync();
+                    }
+                    if (lane == 0 && Lda < -tolG) ev = keymin(ev, KeyMin{Lda, N + w - M});
+                }
+            }
+        }
+    }
+    ev = wave_keymin(ev);
+    if (ev.v < INF) {  // release the single tightest one (:175-184)
+        if (ev.ord < N) {
+            const int jv = ev.ord;
+            st_set(S.Sp, jv, SSQP_IN);
+            const double zr = dense_get(S.zd, jv);
+            if (zr != 0.0) {  // B loses a column with a nonzero weight
+                bound_shift(C, S.hq, S.bEv, jv, -zr);
+                S.cDirty = true;
+                C.sRead += 8ll * N + 64ll * MJ;
+            }
+            S.appJ = jv;
+        } else {
+            S.Emask &= ~(1u << (ev.ord - N));
+        }
+        if (trace && lane == 0) *trace = ssqp_trace{K, W, 2, ev.ord + 1};
+        return W_CONTINUE;
+    }
+    // ---- optimal: polishSz!  SSQP.jl:10-32
+    {
+        unsigned long long sn[2] = {0ull, 0ull};
+        bool snap[2] = {false, false}, sup[2] = {false, false};
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + KSLOT * t;
+            if (r < K) {
+                const double zi = R.zF[t];
+                if (fabs(zi - R.dr[t]) < tol) {
+                    R.zF[t] = R.dr[t];
+                    snap[t] = true;
+                } else if (fabs(zi - R.ur[t]) < tol) {
+                    R.zF[t] = R.ur[t];
+                    snap[t] = true;
+                    sup[t] = true;
+                }
+            }
+            sn[t] = __ballot(snap[t]);
+            const unsigned long long su = __ballot(sup[t]);
+            unsigned long long mm = sn[t];
+            while (mm) {
+                const int l = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                const int jv = __builtin_amdgcn_readlane(R.ord[t], l);
+                st_set(S.Sp, jv, ((su >> l) & 1ull) ? SSQP_UP : SSQP_DN);
+            }
+        }
+        unsigned em = 0;
+#pragma unroll
+        for (int w = 0; w < MJX; ++w) {
+            if (w >= M && w < MJ) {  // S[N+j] = |g_j - G[j,:] z| < tol ? EO : OE   (:28-30)
+                double sz = 0.0;
+#pragma unroll
+                for (int t = 0; t < SL; ++t) {
+                    const int r = lane + KSLOT * t;
+                    sz = (r < K) ? fma(R.X[w][t], R.zF[t], sz) : sz;
+                }
+                sz = wave_sum(sz);
+                const double res = readlane_f64(S.bEv, w) - sz;
+                if (fabs(res) < tol) em |= 1u << (w - M);
+            }
+        }
+        S.Emask = em;
+    }
+    if (trace && lane == 0) *trace = ssqp_trace{K, W, 3, 0};
+    C.ret = C.iter;  // SSQP.jl:374
+    return W_BREAK;
+}
+
+// bring the kept factor in line with the decisions of the last pass
+template <int SL>
+__device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &S) {
+    const int lane = lane_id();
+    Rows &R = S.R;
+    const int MJ = C.MJ;
+    const int ndel = __popcll(S.del0) + __popcll(S.del1);
+    if (ndel > 0) {
+        const bool single = (ndel == 1);
+        // highest row first: deleting row p leaves the rows below p in place
+        if (SL == 2) {
+            unsigned long long dm = S.del1;
+            while (dm) {
+                const int pl = 63 - __clzll(dm);
+                dm &= ~(1ull << pl);
+                delete_var<SL>(L, R, S.K, pl + KSLOT, MJ, single);
+            }
+        }
+        {
+            unsigned long long dm = S.del0;
+            while (dm) {
+                const int pl = 63 - __clzll(dm);
+                dm &= ~(1ull << pl);
+                delete_var<SL>(L, R, S.K, pl, MJ, single);
+            }
+        }
+        S.del0 = S.del1 = 0ull;
+        if (S.K > 0) {
+            if (S.cDirty) regather_c<SL>(R, S.K, S.hq);
+            const unsigned cols = ((1u << MJ) - 1u) | (1u << CC);
+            border_sweep<SL>(L.F, R, S.K, cols);
+            if (!single) recompute_H_all<SL>(L, R, S.K, MJ);
+            else if (S.cDirty) recompute_H_c<SL>(L, R, S.K, MJ);
+            S.cDirty = false;
+        } else {
+            for (int e = lane; e < NR * NR; e += 64) L.H[e] = 0.0;
+            wave_sync();
+        }
+    }
+    if (S.appJ >= 0 || S.appAll) {
+        if (S.cDirty && S.K > 0) {  // c changed for the rows already in the factor
+            regather_c<SL>(R, S.K, S.hq);
+            border_sweep<SL>(L.F, R, S.K, 1u << CC);
+            recompute_H_c<SL>(L, R, S.K, MJ);
+        }
+        S.cDirty = false;
+        if (S.appJ >= 0) {
+            if (S.K + 1 > C.RC) return W_HANDOVER;
+            if (!append_var<SL>(C, L, R, S.K, S.appJ, S.hq, S.zd)) {
+                C.ret = -1;
+                C.det = SSQP_DETAIL_POSDEF_V;
+                return W_BREAK;
+            }
+            S.appJ = -1;
+        } else {  // every IN variable, by increasing index (findall order, SSQP.jl:276)
+            S.appAll = false;
+#pragma unroll
+            for (int m = 0; m < NCH; ++m) {
+                const unsigned long long mx = __ballot(2 * lane + 128 * m < C.N && st_of(S.Sp, 2 * m) == SSQP_IN);
+                const unsigned long long my = __ballot(2 * lane + 128 * m < C.N && st_of(S.Sp, 2 * m + 1) == SSQP_IN);
+                unsigned long long any = mx | my;
+                while (any) {
+                    const int l = __ffsll((long long)any) - 1;
+                    any &= any - 1;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        if (((e ? my : mx) >> l) & 1ull) {
+                            const int jv = 2 * l + 128 * m + e;
+                            // (variables that already have a row are not in this state: the factor is empty)
+                            if (S.K + 1 > C.RC || S.K + 1 > 64 * SL - 1) return W_HANDOVER;
+                            if (!append_var<SL>(C, L, R, S.K, jv, S.hq, S.zd)) {
+                                C.ret = -1;
+                                C.det = SSQP_DETAIL_POSDEF_V;
+                                return W_BREAK;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    } else if (S.cDirty && S.K > 0) {  // only hq changed (cannot happen without a change of F today; kept for safety)
+        regather_c<SL>(R, S.K, S.hq);
+        border_sweep<SL>(L.F, R, S.K, 1u << CC);
+        recompute_H_c<SL>(L, R, S.K, MJ);
+        S.cDirty = false;
+    }
+    return W_CONTINUE;
+}
+
+__device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, const WLds &L, double *gscr) {
+    const int lane = lane_id();
+    const int N = P.N, M = P.M, J = P.J, MJ = P.MJ;
+    WCtx C;
+    C.N = N; C.M = M; C.J = J; C.MJ = MJ;
+    C.tol = P.tol; C.tolG = P.tolG;
+    C.V = P.V + (size_t)prob * P.sV;
+    C.Ct = P.Ct + (size_t)prob * P.sCt;
+    C.rhs = P.rhs + (size_t)prob * P.sRhs;
+    C.q = P.q + (size_t)prob * P.sq;
+    C.dlo = P.d + (size_t)prob * P.sd;
+    C.uhi = P.u + (size_t)prob * P.su;
+    C.trace = P.trace ? P.trace + (size_t)prob * P.ntrace : nullptr;
+    C.ntrace = P.ntrace;
+    C.RC = P.waveRC;
+    C.iter = 0; C.ret = 0; C.det = SSQP_DETAIL_NONE;
+    C.sBytes = 0; C.sRead = 0; C.sFlops = 0; C.sK3 = 0; C.maxK = 0;
+    int32_t *Sg = P.S + (size_t)prob * (N + J);
+    const double tol = P.tol;
+
+    WState S;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        S.R.ord[t] = 0; S.R.rank[t] = 0;
+        S.R.zF[t] = S.R.ur[t] = S.R.dr[t] = 0.0;
+        S.R.dg[t] = 1.0; S.R.rd[t] = 1.0; S.R.cF[t] = 0.0;
+#pragma unroll
+        for (int w = 0; w < MJX; ++w) S.R.X[w][t] = 0.0;
+#pragma unroll
+        for (int w = 0; w < NR; ++w) S.R.Y[w][t] = 0.0;
+    }
+    S.Sp = 0;
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        const int r = 2 * lane + 128 * m;
+        S.zd[m] = (r < N) ? *reinterpret_cast<const double2 *>(P.x0 + (size_t)prob * N + r) : make_double2(0.0, 0.0);
+        const int s0 = (r < N) ? Sg[r] : SSQP_DN, s1 = (r < N) ? Sg[r + 1] : SSQP_DN;
+        S.Sp |= ((unsigned)s0 & 15u) << (8 * m);
+        S.Sp |= ((unsigned)s1 & 15u) << (8 * m + 4);
+        S.hq[m] = make_double2(0.0, 0.0);
+    }
+    {
+        const int sj = (lane < J) ? Sg[N + lane] : SSQP_OE;
+        S.Emask = (unsigned)__ballot(sj == SSQP_EO);
+    }
+    S.bEv = 0.0;
+    S.K = 0;
+    S.hbValid = false;
+    S.cDirty = false;
+    S.del0 = S.del1 = 0ull;
+    S.appJ = -1;
+    S.appAll = true;
+    for (int e = lane; e < NR * NR; e += 64) L.H[e] = 0.0;
+    wave_sync();
+    C.sRead += 8ll * N + 4ll * (N + J);
+
+    bool handover = false;
+    for (;;) {
+        C.iter += 1;
+        if (C.iter > P.maxIter) {  // SSQP.jl:271-274
+            C.ret = -C.iter;
+            break;
+        }
+        ssqp_trace *trace = (C.trace && C.iter <= C.ntrace) ? C.trace + (C.iter - 1) : nullptr;
+        if (!S.hbValid) {
+            refresh_caches(C, S.hq, S.bEv, S.zd, S.Sp);
+            S.hbValid = true;
+            S.cDirty = true;
+        }
+        // rows the pass will have: K - deletes + appends
+        int Knew = S.K - (__popcll(S.del0) + __popcll(S.del1)) + (S.appJ >= 0 ? 1 : 0);
+        if (S.appAll) {
+            int nin = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                nin += __popcll(__ballot(2 * lane + 128 * (k >> 1) < N && st_of(S.Sp, k) == SSQP_IN));
+            Knew = nin;
+        }
+        if (Knew > C.RC) {
+            handover = true;
+            break;
+        }
+        const bool two = (S.K > 63) || (Knew > 63);
+        int act;
+        if (two) act = wave_sync_factor<2>(C, L, S);
+        else act = wave_sync_factor<1>(C, L, S);
+        if (act == W_BREAK) break;
+        if (act == W_HANDOVER) {
+            handover = true;
+            break;
+        }
+        const int K = S.K;
+        if (K == 0) {  // ---------------------------------------- freeK!  SSQP.jl:35-59
+            // p = V z + q: with no free variable this is the cached hq
+            int flag = 0;
+            double pa = 0.0;
+            unsigned rel = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = 2 * lane + 128 * (k >> 1) + (k & 1);
+                const double pp = (k & 1) ? S.hq[k >> 1].y : S.hq[k >> 1].x;
+                const int s = st_of(S.Sp, k);
+                if (i < N && ((pp >= -tol && s == SSQP_UP) || (pp <= tol && s == SSQP_DN))) {  // :41-47
+                    flag = 1;
+                    pa = fmax(pa, fabs(pp));
+                    rel |= 1u << k;
+                }
+            }
+            C.sBytes += 8ll * N * N + 16ll * N + 4ll * (N + J);
+            C.sFlops += 2ll * N * N;
+            const bool any = __ballot(flag) != 0ull;
+            bool done = !any;
+            if (any) {
+                const double pm = wave_max(pa);
+                if (pm <= tol) done = true;  // all movable are optimal: statuses restored (:52-55)
+            }
+            if (done) {
+                if (trace && lane == 0) *trace = ssqp_trace{0, 0, 3, 0};
+                C.ret = C.iter;  // SSQP.jl:281 (no polishSz! on this exit)
+                break;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if ((rel >> k) & 1u) S.Sp &= ~(15u << (4 * k));  // -> IN (code 0)
+            S.appAll = true;
+            S.hbValid = false;  // variables with z != 0 may have left B
+            if (trace && lane == 0) *trace = ssqp_trace{0, 0, 0, 0};
+            continue;
+        }
+        if (K > C.maxK) C.maxK = K;
+        if (two) act = wave_pass<2>(C, L, S, gscr);
+        else act = wave_pass<1>(C, L, S, gscr);
+        if (act == W_BREAK) break;
+    }
+
+    // ---- results: z (free variables from their rows, bound ones from the dense copy / the bounds), S, status
+    const bool polished = (C.ret > 0) && (S.K > 0);
+    double *zg = P.z + (size_t)prob * N;
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        const int r = 2 * lane + 128 * m;
+        if (r < N) {
+            double2 zz = S.zd[m];
+            const int s0 = st_of(S.Sp, 2 * m), s1 = st_of(S.Sp, 2 * m + 1);
+            if (polished) {  // polishSz!: DN -> d, UP -> u  (SSQP.jl:12-16)
+                const double2 dd = *reinterpret_cast<const double2 *>(C.dlo + r);
+                const double2 uu = *reinterpret_cast<const double2 *>(C.uhi + r);
+                zz.x = (s0 == SSQP_DN) ? dd.x : ((s0 == SSQP_UP) ? uu.x : zz.x);
+                zz.y = (s1 == SSQP_DN) ? dd.y : ((s1 == SSQP_UP) ? uu.y : zz.y);
+            }
+            *reinterpret_cast<double2 *>(zg + r) = zz;
+            Sg[r] = s0;
+            Sg[r + 1] = s1;
+        }
+    }
+    if (lane < J) Sg[N + lane] = ((S.Emask >> lane) & 1u) ? SSQP_EO : SSQP_OE;
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int r = lane + KSLOT * t;
+        if (r < S.K) zg[S.R.ord[t]] = S.R.zF[t];  // (a variable snapped by polishSz! carries its bound in zF already)
+    }
+    if (lane == 0) {
+        if (P.stats) {
+            ssqp_stats st;
+            const long long done = handover ? C.iter - 1 : (C.iter > P.maxIter ? P.maxIter : C.iter);
+            st.iters = done;
+            st.alg_bytes = C.sBytes;
+            st.read_bytes = C.sRead;
+            st.alg_flops = C.sFlops;
+            st.sum_k3 = C.sK3;
+            st.max_k = C.maxK;
+            st.path = 1 | 4 | 16;  // LDS factor, kept-factor engine, wavefront kernel
+            P.stats[prob] = st;
+        }
+        if (handover) {
+            P.fbIter[prob] = C.iter - 1;  // passes completed
+            const unsigned slot = atomicAdd(P.fbCount, 1u);
+            P.fbList[slot] = prob;
+        } else {
+            P.status[prob] = C.ret;
+            if (P.detail) P.detail[prob] = C.det;
+        }
+    }
+    wave_sync();
+}
+
+__global__ __launch_bounds__(64, 1) void ssqp_wave_kernel(SolveParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    WLds L;
+    {
+        double *d0 = reinterpret_cast<double *>(smem);
+        const int rc = P.waveRC;
+        const int r1 = rc > 64 ? rc - 64 : 0;
+        int o = 0;
+        L.F.L0 = d0 + o; o += 2080;
+        L.F.L1 = d0 + o; o += rc * r1 + 2;
+        L.F.R1 = r1 > 0 ? r1 : 1;
+        L.H = d0 + o; o += NR * NR;
+        L.Hs = d0 + o; o += MJX * MJX + 1;
+        L.tr = d0 + o; o += MJX * MJX + 1;
+        L.tv = d0 + o; o += 16;
+        L.aLrow = d0 + o; o += 16;
+        L.yn = d0 + o; o += 16;
+        L.ra = reinterpret_cast<int16_t *>(d0 + o);
+    }
+    double *gscr = P.wscratch + (size_t)blockIdx.x * P.wscratchStride;
+    for (;;) {
+        int prob = 0;
+        if (threadIdx.x == 0) prob = (int)atomicAdd(P.queue, 1u);
+        prob = __builtin_amdgcn_readfirstlane(prob);
+        if (prob >= P.nprob) break;
+        wave_solve_one(P, prob, L, gscr);
+    }
+}
+
+bool wave_kernel_applies(int N, int M, int J) {
+    return (N % 2 == 0) && N >= 2 && N <= WAVE_MAXN && (M + J) <= WAVE_MJ;
+}
+int wave_lds_bytes(int rc) {
+    const int r1 = rc > 64 ? rc - 64 : 0;
+    const int dbl = 2080 + rc * r1 + 2 + NR * NR + 2 * (MJX * MJX + 1) + 16 * 3 + 8;
+    return dbl * 8;
+}
+size_t wave_scratch_doubles(int N, int M, int J) {
+    (void)N;
+    const size_t W = (size_t)(M + J);
+    return 128 * W + W * W + W + 64;
+}
+hipError_t launch_solve_wave(const SolveParams &P, int grid, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ssqp_wave_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, P.waveLdsBytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ssqp_wave_kernel, dim3(grid), dim3(64), (size_t)P.waveLdsBytes, stream, P);
+    return hipGetLastError();
+}
+
+}  // namespace ssqp

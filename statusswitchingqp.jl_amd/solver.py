@@ -51,6 +51,32 @@ class Context:
     def handle(self):
         return self._h
 
+    def set_option(self, name, value):
+        """Per-context switch (ssqp_ctx_set_option): wave_kernel, wave_qp_per_cu, incremental, dense_gamma, wg_per_cu."""
+        _capi.check(_capi.lib().ssqp_ctx_set_option(self._h, name.encode(), int(value)), self._h)
+
+    def get_option(self, name):
+        v = C.c_int(0)
+        _capi.check(_capi.lib().ssqp_ctx_get_option(self._h, name.encode(), C.byref(v)), self._h)
+        return v.value
+
+    def options(self, **kw):
+        """Context manager: set options, restore the previous values on exit."""
+        ctx = self
+
+        class _Scope:
+            def __enter__(self):
+                self.old = {k: ctx.get_option(k) for k in kw}
+                for k, v in kw.items():
+                    ctx.set_option(k, v)
+                return ctx
+
+            def __exit__(self, *exc):
+                for k, v in self.old.items():
+                    ctx.set_option(k, v)
+                return False
+        return _Scope()
+
     def last_kernel_ms(self):
         ms = C.c_float(0)
         _capi.check(_capi.lib().ssqp_last_kernel_ms(self._h, C.byref(ms)), self._h)
@@ -274,9 +300,17 @@ class DeviceBatch:
         Arrays given with a leading dimension of 1 are shared by every problem of the batch (stride 0)."""
         torch = self.torch
         cs = _csettings(settings)
-        self.S.copy_(self.S0)  # S is in/out
+        # S is in/out: the reset runs on the SAME stream as the launch (a raw hipStream_t is wrapped, so the copy
+        # cannot race with the kernels of this or the previous launch on that stream)
         if stream is None:
-            stream = torch.cuda.current_stream(self.S.device).cuda_stream
+            tstream = torch.cuda.current_stream(self.S.device)
+        elif isinstance(stream, int):
+            tstream = torch.cuda.ExternalStream(stream, device=self.S.device)
+        else:
+            tstream = stream
+        with torch.cuda.stream(tstream):
+            self.S.copy_(self.S0)
+        stream = tstream.cuda_stream
         t = self.t
         per = dict(V=self.N * self.N, A=self.M * self.N, G=self.J * self.N, q=self.N, b=self.M, g=self.J, d=self.N,
                    u=self.N)

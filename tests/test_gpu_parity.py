@@ -16,17 +16,29 @@ from conftest import assert_parity, colmajor, oracle_batch
 pytestmark = pytest.mark.gpu
 
 
-def run_cfg(pkg, orc, cfg, nprob, seed0=None, rtol=1e-10):
+def run_cfg(pkg, orc, cfg, nprob, seed0=None, rtol=1e-10, opts=None, both=True):
+    """HIP path vs oracle on one synthetic family.  `opts` = context options for the run (ssqp_ctx_set_option).
+    With the default options a shape the wavefront-per-QP kernel takes is ALSO run through the workgroup kernel
+    alone (wave_kernel=0): both product kernels must match the oracle.  Returns the stats of the first run."""
     prob = pkg.generate_batch(cfg, nprob, seed0 if seed0 is not None else pkg.BASE_SEED)
     x0, S0, st = pkg.phase1_batch(prob)
     assert (st == 1).all()
-    z, S, status, detail, stats = pkg.solveQP_batch(prob, S0, x0, want_stats=True)
     zo, So, sto, deto, _ = oracle_batch(orc, prob, S0, x0)
     assert (sto > 0).all()
-    rel = assert_parity(z, S, status, zo, So, sto, rtol)
-    assert (detail == 0).all()
-    assert np.array_equal(stats["iters"], sto)
-    return rel, stats
+    ctx = pkg.default_context()
+    runs = [dict(opts or {})]
+    if opts is None and both and cfg.N % 2 == 0 and cfg.N <= 512 and cfg.M + cfg.J <= 11:
+        runs.append(dict(wave_kernel=0))
+    first = None
+    for o in runs:
+        with ctx.options(**o):
+            z, S, status, detail, stats = pkg.solveQP_batch(prob, S0, x0, want_stats=True)
+        rel = assert_parity(z, S, status, zo, So, sto, rtol)
+        assert (detail == 0).all()
+        assert np.array_equal(stats["iters"], sto)
+        if first is None:
+            first = (rel, stats)
+    return first
 
 
 def test_reference_kat_3x3(pkg):
@@ -66,14 +78,15 @@ def test_cfg2_n512(pkg, orc):
 
 def test_cfg3_n256_large_k_global_arena(pkg, orc):
     """K grows to ~220: the kept factor outgrows LDS and migrates to the workgroup's global arena (path bit 8)"""
-    rel, stats = run_cfg(pkg, orc, pkg.CONFIGS["cfg3"], 8)
+    rel, stats = run_cfg(pkg, orc, pkg.CONFIGS["cfg3"], 8, opts=dict(wave_kernel=0))
     assert stats["max_k"].max() > 180
     assert ((stats["path"] & 8) != 0).all()
-    os.environ["SSQP_INCREMENTAL"] = "0"          # from-scratch factorisation out of the global arena
-    try:
-        rel, stats = run_cfg(pkg, orc, pkg.CONFIGS["cfg3"], 2)
-    finally:
-        os.environ["SSQP_INCREMENTAL"] = "1"
+    # default routing: the wavefront kernel starts every QP and hands it over when K outgrows its factor (bit 32)
+    rel, stats = run_cfg(pkg, orc, pkg.CONFIGS["cfg3"], 8, both=False)
+    assert stats["max_k"].max() > 180
+    assert ((stats["path"] & 16) != 0).all() and ((stats["path"] & 32) != 0).all()
+    # from-scratch factorisation out of the global arena
+    rel, stats = run_cfg(pkg, orc, pkg.CONFIGS["cfg3"], 2, opts=dict(incremental=0))
     assert ((stats["path"] & 2) != 0).all()
 
 
@@ -164,11 +177,8 @@ def test_full_batch_properties_cfg4(pkg, orc):
     # (polishSz! may relabel a near-bound IN variable, so the warm start can need a couple of passes)
     assert np.array_equal(S2, S) and (status2 >= 1).all() and (status2 <= 3).all() and np.abs(z2 - z).max() < 1e-9
     # the dense formulation of the gamma pass (every column of V read, as SSQP.jl:352) takes the same decisions
-    os.environ["SSQP_DENSE_GAMMA"] = "1"
-    try:
+    with pkg.default_context().options(dense_gamma=1):
         z3, S3, status3, _ = pkg.solveQP_batch(prob, S0, x0)
-    finally:
-        os.environ["SSQP_DENSE_GAMMA"] = "0"
     assert np.array_equal(S3, S) and np.array_equal(status3, status) and np.abs(z3 - z).max() < 1e-12
 
 
@@ -200,13 +210,11 @@ def test_incremental_and_from_scratch_agree(pkg, orc):
     """the kept-factor engine (default) and the from-scratch factorisation (SSQP_INCREMENTAL=0) take the same
     decisions as the oracle"""
     cfg = pkg.GenConfig(160, 1, 5, 320, 1e-3, 0.06, 0.98, 0.1)
-    for inc in ("1", "0"):
-        os.environ["SSQP_INCREMENTAL"] = inc
-        try:
-            rel, stats = run_cfg(pkg, orc, cfg, 48)
-        finally:
-            os.environ["SSQP_INCREMENTAL"] = "1"
-        assert (((stats["path"] & 4) != 0).all()) == (inc == "1")
+    for inc in (1, 0):
+        rel, stats = run_cfg(pkg, orc, cfg, 48, opts=dict(incremental=inc, wave_kernel=0))
+        assert (((stats["path"] & 4) != 0).all()) == (inc == 1)
+    rel, stats = run_cfg(pkg, orc, cfg, 48, both=False)      # default routing: the wavefront kernel
+    assert ((stats["path"] & 16) != 0).all()
 
 
 def _mutate(prob, rng, kind):
