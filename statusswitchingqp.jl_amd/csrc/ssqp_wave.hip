@@ -29,6 +29,25 @@
 #include "ssqp_device.h"
 
 namespace ssqp {
+
+// ---- diagnostic build only (-DSSQP_PHASE_PROFILE): cycles per phase of the wavefront kernel ----
+#ifdef SSQP_PHASE_PROFILE
+// (accumulated in registers and flushed once per QP: an atomic per stamp would sit in front of every later load of
+// the phase -- vector memory operations complete in order -- and charge its own round trip to that phase)
+__device__ unsigned long long g_wphase[64];
+#define WPH_DECL unsigned long long wph_t = __builtin_amdgcn_s_memtime()
+#define WPH(slot)                                                        \
+    do {                                                                 \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();      \
+        C.ph[(slot)] += t_ - wph_t;                                      \
+        C.pn[(slot)] += 1;                                               \
+        wph_t = __builtin_amdgcn_s_memtime();                            \
+    } while (0)
+#else
+#define WPH_DECL do { } while (0)
+#define WPH(slot) do { } while (0)
+#endif
+
 namespace wv {
 
 constexpr int MJX = WAVE_MJ;  // constraint rows carried (M + J <= MJX)
@@ -591,6 +610,10 @@ struct WCtx {
     int det;
     long long sBytes, sRead, sFlops, sK3;
     int maxK;
+#ifdef SSQP_PHASE_PROFILE
+    unsigned long long ph[16];
+    unsigned pn[16];
+#endif
 };
 
 enum { W_CONTINUE = 0, W_BREAK = 1, W_HANDOVER = 2 };
@@ -658,6 +681,9 @@ __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int 
                                            const double2 (&zd)[NCH]) {
     const int lane = lane_id();
     const int N = C.N, MJ = C.MJ;
+    // everything the new row needs from memory is requested before the factor sweep: one round trip, hidden
+    const double cj = C.Ct[(size_t)(lane < MJ ? lane : 0) * N + j];  // column j of [A;G], row w in lane w
+    const double uj = C.uhi[j], dj = C.dlo[j];
     double lnew[2];
     const double dnew = append_row<SL>(L.F, R, K, j, C.V, N, lnew);
     if (!(dnew > 0.0)) return false;
@@ -671,8 +697,6 @@ __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int 
         below += __popcll(__ballot(lt));
         R.rank[t] = ((r < K) && (R.ord[t] > j)) ? R.rank[t] + 1 : R.rank[t];
     }
-    const double cj = C.Ct[(size_t)(lane < MJ ? lane : 0) * N + j];  // column j of [A;G], row w in lane w
-    const double uj = C.uhi[j], dj = C.dlo[j];
     const double zj = dense_get(zd, j), hj = dense_get(hq, j);
     set_row_i<SL>(R.ord, K, j);
     set_row_i<SL>(R.rank, K, below);
@@ -733,7 +757,7 @@ __device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p
             double s = 0.0;
             if (w < MJ || w == CC) {  // uniform
 #pragma unroll
-                for (int t = 0; t < SL; ++t) s = fma(R.Y[w][t], frd[t], s);
+                for (int t = 0; t < SL; ++t) s = (lane + KSLOT * t < K) ? fma(R.Y[w][t], frd[t], s) : s;
                 s = wave_sum(s);
             }
             if (lane == 0) L.yn[w] = s;
@@ -854,6 +878,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
     const int K = S.K;
     ssqp_trace *trace = (C.trace && C.iter <= C.ntrace) ? C.trace + (C.iter - 1) : nullptr;
 
+    WPH_DECL;
     // ---- active rows (SSQP.jl:288-294): all equalities, then the inequalities with status EO
     const unsigned act = ((1u << M) - 1u) | (S.Emask << M);
     const int W0 = __popc(act);
@@ -864,6 +889,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
         else kept = rank_filter<2>(R, S.bEv, act, K, tol);
     }
     const int W = __popc(kept);
+    WPH(0);  // rank filter
     // kept row ids in order; alphaL by row id
     if (lane < MJX + 1) L.aLrow[lane] = 0.0;
     {
@@ -896,6 +922,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
         if (lane < W) L.aLrow[L.ra[lane]] = -lam;
         wave_sync();
     }
+    WPH(1);  // Schur gather + lambda
     // ---- alpha = -V_FF^-1 (AE' alphaL + c):  v = D^-1 (Y_A alphaL + y_c), alpha = -L'^-1 v   (SSQP.jl:329-331)
     double v[2] = {0.0, 0.0};
 #pragma unroll
@@ -914,6 +941,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
         v[t] = (r < K) ? v[t] * R.rd[t] : 0.0;
     }
     back_sweep<SL>(L.F, K, v);
+    WPH(2);  // v + back substitution
     double alpha[2], p[2];
     double pa = 0.0;
     int pnan = 0;
@@ -937,6 +965,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
         C.sK3 += k * k * k;
     }
 
+    WPH(3);  // p, norm, accounting
     if (pinf > tolG && !anyNan) {  // ------------------------ aStep!  SSQP.jl:61-134
         double Lr[2];
         double lmin = INF;
@@ -974,6 +1003,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
         lmin = fmin(lmin, lin);
         const double L1 = wave_min(lmin);
         C.sFlops += 2ll * (J - __popc(S.Emask)) * (N + K);
+        WPH(4);  // aStep ratios + min
         if (L1 < 1.0) {  // blocked  (:98-127)
             int firstId = 0x7fffffff;
             unsigned long long dm[2] = {0ull, 0ull};
@@ -1016,6 +1046,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
                     }
                 }
             }
+            WPH(5);  // blocked: switches + bound shifts
             S.del0 = dm[0];
             S.del1 = dm[1];
             if (trace) {
@@ -1039,21 +1070,32 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
         }
     }
 
+    WPH(6);  // full step bookkeeping
     // ---- multipliers: gamma = V[B,F] alpha + V[B,B] zB + q[B] + AB' alphaL  (SSQP.jl:352)
     //      = hq + V[:,F] alpha + [A;G][kept,:]' alphaL on the bound variables
     double2 gam[NCH];
 #pragma unroll
     for (int m = 0; m < NCH; ++m) gam[m] = S.hq[m];
     {
-        constexpr int NB = 4;  // columns in flight
-        for (int r0 = 0; r0 < K; r0 += NB) {
+        // one list: the K free columns of V (weights alpha) and the W kept rows of [A;G] (weights alphaL), NB at a
+        // time with all their loads in flight together
+        constexpr int NB = 4;
+        const int ncolG = K + W;
+        for (int e0 = 0; e0 < ncolG; e0 += NB) {
             const double *__restrict__ col[NB];
             double wj[NB];
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
-                const int r = (r0 + c < K) ? r0 + c : r0;
-                col[c] = C.V + (size_t)rbcast_i<SL>(R.ord, r) * N;
-                wj[c] = (r0 + c < K) ? rbcast<SL>(alpha, r) : 0.0;
+                const int e = (e0 + c < ncolG) ? e0 + c : e0;
+                if (e < K) {  // uniform
+                    col[c] = C.V + (size_t)rbcast_i<SL>(R.ord, e) * N;
+                    wj[c] = rbcast<SL>(alpha, e);
+                } else {
+                    const int rid = L.ra[e - K];
+                    col[c] = C.Ct + (size_t)rid * N;
+                    wj[c] = L.aLrow[rid];
+                }
+                wj[c] = (e0 + c < ncolG) ? wj[c] : 0.0;
             }
             double2 vv[NCH][NB];
 #pragma unroll
@@ -1074,9 +1116,6 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
                 }
             }
         }
-#pragma unroll
-        for (int w = 0; w < MJX; ++w)
-            if ((kept >> w) & 1u) axpy_dense(gam, C.Ct + (size_t)w * N, L.aLrow[w], N);
         C.sRead += 8ll * N * (K + W);
     }
     {
@@ -1085,6 +1124,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
         C.sFlops += 2ll * r * r + 2ll * r * K;
     }
 
+    WPH(7);  // gamma pass
     // ---- KKTchk!  SSQP.jl:136-188
     KeyMin ev{INF, 0x7fffffff};
 #pragma unroll
@@ -1179,6 +1219,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
             }
         }
     }
+    WPH(8);  // KKT scan
     ev = wave_keymin(ev);
     if (ev.v < INF) {  // release the single tightest one (:175-184)
         if (ev.ord < N) {
@@ -1194,6 +1235,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
         } else {
             S.Emask &= ~(1u << (ev.ord - N));
         }
+        WPH(9);  // release + bound shift
         if (trace && lane == 0) *trace = ssqp_trace{K, W, 2, ev.ord + 1};
         return W_CONTINUE;
     }
@@ -1253,6 +1295,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
     const int lane = lane_id();
     Rows &R = S.R;
     const int MJ = C.MJ;
+    WPH_DECL;
     const int ndel = __popcll(S.del0) + __popcll(S.del1);
     if (ndel > 0) {
         const bool single = (ndel == 1);
@@ -1273,6 +1316,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
                 delete_var<SL>(L, R, S.K, pl, MJ, single);
             }
         }
+        WPH(10);  // deletes (update + downdate + compaction + shifts)
         S.del0 = S.del1 = 0ull;
         if (S.K > 0) {
             if (S.cDirty) regather_c<SL>(R, S.K, S.hq);
@@ -1286,12 +1330,14 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
             wave_sync();
         }
     }
+    if (ndel > 0) WPH(11);  // border sweep + H column after deletes
     if (S.appJ >= 0 || S.appAll) {
         if (S.cDirty && S.K > 0) {  // c changed for the rows already in the factor
             regather_c<SL>(R, S.K, S.hq);
             border_sweep<SL>(L.F, R, S.K, 1u << CC);
             recompute_H_c<SL>(L, R, S.K, MJ);
         }
+        WPH(12);  // c refresh before an append
         S.cDirty = false;
         if (S.appJ >= 0) {
             if (S.K + 1 > C.RC) return W_HANDOVER;
@@ -1300,6 +1346,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
                 C.det = SSQP_DETAIL_POSDEF_V;
                 return W_BREAK;
             }
+            WPH(13);  // one append
             S.appJ = -1;
         } else {  // every IN variable, by increasing index (findall order, SSQP.jl:276)
             S.appAll = false;
@@ -1353,6 +1400,14 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     C.RC = P.waveRC;
     C.iter = 0; C.ret = 0; C.det = SSQP_DETAIL_NONE;
     C.sBytes = 0; C.sRead = 0; C.sFlops = 0; C.sK3 = 0; C.maxK = 0;
+#ifdef SSQP_PHASE_PROFILE
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        C.ph[k] = 0;
+        C.pn[k] = 0;
+    }
+    const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+#endif
     int32_t *Sg = P.S + (size_t)prob * (N + J);
     const double tol = P.tol;
 
@@ -1498,6 +1553,16 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
         const int r = lane + KSLOT * t;
         if (r < S.K) zg[S.R.ord[t]] = S.R.zF[t];  // (a variable snapped by polishSz! carries its bound in zF already)
     }
+#ifdef SSQP_PHASE_PROFILE
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            (void)__hip_atomic_fetch_add(&g_wphase[k], C.ph[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add(&g_wphase[32 + k], (unsigned long long)C.pn[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        (void)__hip_atomic_fetch_add(&g_wphase[31], __builtin_amdgcn_s_memtime() - tq0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
     if (lane == 0) {
         if (P.stats) {
             ssqp_stats st;
@@ -1574,3 +1639,14 @@ hipError_t launch_solve_wave(const SolveParams &P, int grid, hipStream_t stream)
 }
 
 }  // namespace ssqp
+
+#ifdef SSQP_PHASE_PROFILE
+extern "C" int ssqp_debug_wave_phases(unsigned long long *out64, int reset) {
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(ssqp::g_wphase), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        static unsigned long long zero[64];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ssqp::g_wphase), zero, sizeof(zero)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
