@@ -143,6 +143,17 @@ int ssqp_solve_batch_f64(ssqp_ctx *ctx, int nprob, int N, int M, int J, const do
                          const double *x0, double *z, const ssqp_settings *settings,
                          int64_t *status, int32_t *detail, ssqp_stats *stats);
 
+/* The same over SEVERAL contexts -- normally one per GPU of the node (ssqp_ctx_create(dev, ...) for dev = 0..G-1):
+ * the batch is cut into contiguous blocks, context r solves problems [r*ceil(P/G), (r+1)*ceil(P/G)) on its own
+ * GPU from its own host thread, and every block's z, S, status land in the caller's arrays (SURVEY.md section 8e:
+ * independent QPs shard with no exchange; in a one-process host this call IS the final gather).  What a Julia
+ * host binds to solve a Vector{QP} on all GPUs with one ccall.  Two contexts may also share a device. */
+int ssqp_solve_batch_multi_f64(ssqp_ctx *const *ctxs, int nctx, int nprob, int N, int M, int J,
+                               const double *V, const double *A, const double *G, const double *q,
+                               const double *b, const double *g, const double *d, const double *u,
+                               int32_t *S, const double *x0, double *z, const ssqp_settings *settings,
+                               int64_t *status, int32_t *detail, ssqp_stats *stats);
+
 /* Device-resident buffers (all pointers are device pointers on ctx's GPU;
  * stats/trace may be NULL).  Asynchronous on `stream` (a hipStream_t passed
  * as void*; NULL = HIP's default stream); ssqp_sync waits for it.
@@ -180,6 +191,15 @@ int ssqp_phase1_batch_f64(int nprob, int N, int M, int J, const double *A, const
                           const double *b, const double *g, const double *d, const double *u,
                           const ssqp_settings *settingsLP, double *x0, int32_t *S,
                           int32_t *status, int nthreads);
+
+/* The same for a batch whose problem data already sits in HBM: ON the GPU (one workgroup per QP), asynchronous on
+ * `stream`, bit-identical to the host version (same decisions, same summation orders, no FMA contraction), so the loop
+ * that follows runs the same passes.  All pointers are device pointers; needs M + J small enough for the basis
+ * inverse to fit in LDS (SSQP_ERR_UNSUPPORTED otherwise: use the host version).  dstatus as above. */
+int ssqp_phase1_batch_dev_f64(ssqp_ctx *ctx, int nprob, int N, int M, int J, const double *dA, const double *dG,
+                              const double *db, const double *dg, const double *dd, const double *du,
+                              const ssqp_settings *settingsLP, double *dx0, int32_t *dS, int32_t *dstatus,
+                              void *stream);
 
 /* ---- deterministic synthetic problems ---------- */
 /* V = X'X/T + delta*I, X (T x N) iid U(-1/2,1/2) from a SplitMix64 counter

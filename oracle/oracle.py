@@ -57,6 +57,11 @@ def lib():
         _lib.orc_solveQP_warm_batch.restype = C.c_int
         _lib.orc_solveQP_warm_batch.argtypes = [C.c_int] * 4 + [dp] * 8 + [ip, dp, dp, C.POINTER(Settings),
                                                                            C.POINTER(C.c_int64), ip, C.c_int]
+        _lib.orc_solveQP_warm_batch2.restype = C.c_int
+        _lib.orc_solveQP_warm_batch2.argtypes = [C.c_int] * 4 + [dp] * 8 + [ip, dp, dp, C.POINTER(Settings),
+                                                                            C.POINTER(C.c_int64), ip, C.c_int, C.c_int]
+        _lib.orc_lapack_load.restype = C.c_int
+        _lib.orc_lapack_load.argtypes = [C.c_char_p]
         _lib.orc_initQP_batch.restype = C.c_int
         _lib.orc_initQP_batch.argtypes = [C.c_int] * 4 + [dp] * 6 + [C.c_double, dp, ip, ip, C.c_int]
     return _lib
@@ -134,7 +139,30 @@ def solveQP(V, A, G, q, b, g, d, u, mc=1, settings=None, max_trace=0):
     return z, S, int(st), int(det.value), trace
 
 
-def solveQP_warm_batch(V, A, G, q, b, g, d, u, S, x0, settings=None, nthreads=0):
+_lapack_state = None
+
+
+def lapack_available():
+    """Bind dpotrf/dpotri/dgemm/dgemv of the OpenBLAS that scipy bundles (what Julia's LinearAlgebra calls at
+    SSQP.jl:322-331,351-352) into the oracle; False when the library cannot be found."""
+    global _lapack_state
+    if _lapack_state is None:
+        _lapack_state = False
+        try:
+            import glob
+            import scipy
+            cands = glob.glob(os.path.join(os.path.dirname(scipy.__file__), "..", "scipy.libs", "libscipy_openblas*"))
+            cands += glob.glob(os.path.join(os.path.dirname(scipy.__file__), ".libs", "libopenblas*"))
+            for c in cands:
+                if lib().orc_lapack_load(os.path.abspath(c).encode()) == 0:
+                    _lapack_state = True
+                    break
+        except Exception:
+            _lapack_state = False
+    return _lapack_state
+
+
+def solveQP_warm_batch(V, A, G, q, b, g, d, u, S, x0, settings=None, nthreads=0, lapack=False):
     """Back-to-back batch: V (P,N,N) with each V[p] symmetric (so C order == column-major),
     A (P,N,M) = per-problem column-major M x N, G (P,N,J) likewise; vectors (P,len)."""
     P, N = q.shape
@@ -147,9 +175,11 @@ def solveQP_warm_batch(V, A, G, q, b, g, d, u, S, x0, settings=None, nthreads=0)
     detail = np.zeros(P, dtype=np.int32)
     arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (V, A, G, q, b, g, d, u)]
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
-    used = lib().orc_solveQP_warm_batch(P, N, M, J, *[_dp(a) for a in arrs], _ip(S), _dp(x0), _dp(z),
-                                        C.byref(settings), status.ctypes.data_as(C.POINTER(C.c_int64)),
-                                        _ip(detail), nthreads)
+    if lapack and not lapack_available():
+        raise RuntimeError("no LAPACK library to bind (scipy's OpenBLAS not found)")
+    used = lib().orc_solveQP_warm_batch2(P, N, M, J, *[_dp(a) for a in arrs], _ip(S), _dp(x0), _dp(z),
+                                         C.byref(settings), status.ctypes.data_as(C.POINTER(C.c_int64)),
+                                         _ip(detail), nthreads, 1 if lapack else 0)
     return z, S, status, detail, used
 
 

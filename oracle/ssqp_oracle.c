@@ -35,6 +35,7 @@
 
 #ifdef _OPENMP
 #include <omp.h>
+#include <stdio.h>
 #endif
 
 /* src/types.jl:17-23  @enum Status IN DN UP OE EO  (Int32 codes 0..4) */
@@ -65,6 +66,86 @@ typedef struct {
 } orc_trace;
 
 #define IDX(i, j, ld) ((size_t)(i) + (size_t)(j) * (size_t)(ld))
+
+/* ------------------------------------------------------------------------- */
+/* optional LAPACK/BLAS arithmetic (cpu_baseline leg "lapack" of bench.py)     */
+/* ------------------------------------------------------------------------- */
+/* Julia's LinearAlgebra does the dense work of SSQP.jl:322-331,351-352 with OpenBLAS/LAPACK (potrf + potri,
+ * gemm, gemv).  orc_lapack_load() binds the same routines from the OpenBLAS shared library that scipy bundles
+ * (symbols scipy_dpotrf_ ...; plain dpotrf_ ... are tried too), so that the restatement can be TIMED with the
+ * arithmetic the reference actually runs.  Decisions are the same threshold tests; only summation orders differ. */
+#include <dlfcn.h>
+typedef void (*orc_potrf_t)(const char *, const int *, double *, const int *, int *);
+typedef void (*orc_gemm_t)(const char *, const char *, const int *, const int *, const int *, const double *,
+                           const double *, const int *, const double *, const int *, const double *, double *,
+                           const int *);
+typedef void (*orc_gemv_t)(const char *, const int *, const int *, const double *, const double *, const int *,
+                           const double *, const int *, const double *, double *, const int *);
+static struct {
+    void *h;
+    orc_potrf_t potrf, potri;
+    orc_gemm_t gemm;
+    orc_gemv_t gemv;
+} LP;
+static __thread int t_lapack = 0; /* this thread's solves use LP */
+
+static void *lp_sym(void *h, const char *name)
+{
+    char buf[64];
+    snprintf(buf, sizeof buf, "scipy_%s", name);
+    void *f = dlsym(h, buf);
+    return f ? f : dlsym(h, name);
+}
+int orc_lapack_load(const char *path)
+{
+    if (LP.h) return 0;
+    void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return 1;
+    LP.potrf = (orc_potrf_t)lp_sym(h, "dpotrf_");
+    LP.potri = (orc_potrf_t)lp_sym(h, "dpotri_");
+    LP.gemm = (orc_gemm_t)lp_sym(h, "dgemm_");
+    LP.gemv = (orc_gemv_t)lp_sym(h, "dgemv_");
+    void (*setn)(int) = (void (*)(int))lp_sym(h, "openblas_set_num_threads");
+    if (!LP.potrf || !LP.potri || !LP.gemm || !LP.gemv) return 2;
+    if (setn) setn(1); /* one BLAS thread per QP: the parallelism is one QP per core */
+    LP.h = h;
+    return 0;
+}
+static void lp_gemm(char ta, char tb, int m, int n, int k, double al, const double *a, int lda, const double *b,
+                    int ldb, double be, double *c, int ldc)
+{
+    if (m <= 0 || n <= 0) return;
+    if (k <= 0) {
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < m; ++i) c[IDX(i, j, ldc)] = (be == 0.0) ? 0.0 : be * c[IDX(i, j, ldc)];
+        return;
+    }
+    LP.gemm(&ta, &tb, &m, &n, &k, &al, a, &lda, b, &ldb, &be, c, &ldc);
+}
+static void lp_gemv(char t, int m, int n, double al, const double *a, int lda, const double *x, double be, double *y)
+{
+    const int one = 1;
+    const int ylen = (t == 'N') ? m : n;
+    if (ylen <= 0) return;
+    if (m <= 0 || n <= 0) {
+        for (int i = 0; i < ylen; ++i) y[i] = (be == 0.0) ? 0.0 : be * y[i];
+        return;
+    }
+    LP.gemv(&t, &m, &n, &al, a, &lda, x, &one, &be, y, &one);
+}
+/* inv(cholesky(A)) by potrf('U') + potri('U') + mirror; returns potrf's info */
+static int lp_chol_inverse(double *a, int n)
+{
+    int info = 0;
+    const char U = 'U';
+    if (n <= 0) return 0;
+    LP.potrf(&U, &n, a, &n, &info);
+    if (info != 0) return info;
+    LP.potri(&U, &n, a, &n, &info);
+    for (int j = 0; j < n; ++j)
+        for (int i = j + 1; i < n; ++i) a[IDX(i, j, n)] = a[IDX(j, i, n)];
+    return info;
+}
 
 /* ------------------------------------------------------------------------- */
 /* dense helpers (what Julia delegates to LinearAlgebra / LAPACK)             */
@@ -329,6 +410,7 @@ typedef struct {
     /* dense work */
     double *AE, *AB, *bE, *X, *zB, *VFF, *c, *mT, *C, *TC, *VQ, *alpha, *p, *alphaL, *gamma;
     double *tmpW, *tmpK, *lsA, *lsy, *lsx, *pN;
+    double *VBF, *VBB; /* LAPACK mode: the gathers V[B,F], V[B,B] the reference materialises (SSQP.jl:323,352) */
     int32_t *S0;
     event_t *ev;
 } work_t;
@@ -358,6 +440,8 @@ static void work_alloc(work_t *w, int N, int M, int J)
     w->lsA = xm(sizeof(double) * (size_t)N * (W0 + 1));
     w->lsy = xm(sizeof(double) * N); w->lsx = xm(sizeof(double) * (W0 + 1));
     w->pN = xm(sizeof(double) * N);
+    w->VBF = t_lapack ? xm(sizeof(double) * (size_t)N * N) : NULL;
+    w->VBB = t_lapack ? xm(sizeof(double) * (size_t)N * N) : NULL;
     w->S0 = xm(sizeof(int32_t) * (N + J));
     w->ev = xm(sizeof(event_t) * (size_t)(N + J + 1));
 }
@@ -369,6 +453,7 @@ static void work_free(work_t *w)
     free(w->c); free(w->mT); free(w->C); free(w->TC); free(w->VQ); free(w->alpha);
     free(w->p); free(w->alphaL); free(w->gamma); free(w->tmpW); free(w->tmpK);
     free(w->lsA); free(w->lsy); free(w->lsx); free(w->pN); free(w->S0); free(w->ev);
+    free(w->VBF); free(w->VBB);
 }
 
 /* src/SSQP.jl:61-134  aStep!  -- returns -1 (blocked) or +1 (full step) */
@@ -511,6 +596,47 @@ int64_t orc_solveQP_warm(int N, int M, int J, const double *V, const double *A, 
         double *iV = w->VFF;
         for (int b2 = 0; b2 < K; ++b2)
             for (int a2 = 0; a2 < K; ++a2) iV[IDX(a2, b2, K)] = V[IDX(w->iF[a2], w->iF[b2], N)];
+        double *mT = w->mT, *C = w->C, *TC = w->TC, *VQ = w->VQ;
+        double pinf = 0.0;
+        int pnan = 0;
+        if (t_lapack) { /* the same statements with LAPACK/BLAS doing the arithmetic, as LinearAlgebra does */
+            if (lp_chol_inverse(iV, K) != 0) {
+                if (detail) *detail = ORC_POSDEF_V;
+                ret = -1;
+                break;
+            }
+            /* VBF = V[B,F]; c = VBF'*zB + q[F]   :323-324 */
+            for (int k = 0; k < K; ++k) {
+                const double *col = V + (size_t)w->iF[k] * N;
+                for (int r = 0; r < R; ++r) w->VBF[IDX(r, k, R)] = col[w->iB[r]];
+                w->c[k] = q[w->iF[k]];
+            }
+            lp_gemv('T', R, K, 1.0, w->VBF, R > 0 ? R : 1, w->zB, 1.0, w->c);
+            lp_gemm('N', 'T', K, W, K, 1.0, iV, K, AE, W > 0 ? W : 1, 0.0, mT, K);   /* mT = iV*AE'   :325 */
+            lp_gemm('N', 'N', W, W, K, 1.0, AE, W > 0 ? W : 1, mT, K, 0.0, C, W > 0 ? W : 1); /* C = AE*mT :326 */
+            for (int c2 = 0; c2 < W; ++c2)
+                for (int r = c2; r < W; ++r) {
+                    double sv = (C[IDX(r, c2, W)] + C[IDX(c2, r, W)]) / 2;
+                    C[IDX(r, c2, W)] = sv;
+                    C[IDX(c2, r, W)] = sv;
+                }
+            if (W > 0 && lp_chol_inverse(C, W) != 0) {
+                if (detail) *detail = ORC_POSDEF_C;
+                ret = -1;
+                break;
+            }
+            lp_gemm('N', 'N', K, W, W, 1.0, mT, K, C, W > 0 ? W : 1, 0.0, TC, K);   /* TC = mT*C   :329 */
+            memcpy(VQ, iV, sizeof(double) * (size_t)K * K);
+            lp_gemm('N', 'T', K, K, W, -1.0, mT, K, TC, K, 1.0, VQ, K);             /* VQ = iV - mT*TC'   :330 */
+            lp_gemv('N', K, W, 1.0, TC, K, bE, 0.0, w->alpha);                      /* alpha = TC*bE - VQ*c :331 */
+            lp_gemv('N', K, K, -1.0, VQ, K, w->c, 1.0, w->alpha);
+            for (int i = 0; i < K; ++i) {
+                w->p[i] = w->alpha[i] - z[w->iF[i]];
+                double a = fabs(w->p[i]);
+                if (a != a) pnan = 1;
+                if (a > pinf) pinf = a;
+            }
+        } else {
         if (chol_upper(iV, K) != 0) {
             if (detail) *detail = ORC_POSDEF_V;
             ret = -1;
@@ -525,7 +651,6 @@ int64_t orc_solveQP_warm(int N, int M, int J, const double *V, const double *A, 
             w->c[k] = s + q[w->iF[k]];
         }
         /* mT = iV*AE' (K x W)   :325 */
-        double *mT = w->mT, *C = w->C, *TC = w->TC, *VQ = w->VQ;
         for (int r = 0; r < W; ++r)
             for (int i = 0; i < K; ++i) {
                 double s = 0.0;
@@ -568,8 +693,6 @@ int64_t orc_solveQP_warm(int N, int M, int J, const double *V, const double *A, 
                 VQ[IDX(i, j2, K)] = iV[IDX(i, j2, K)] - s;
             }
         /* alpha = TC*bE - VQ*c ; p = alpha - z[F]   :331-332 */
-        double pinf = 0.0;
-        int pnan = 0;
         for (int i = 0; i < K; ++i) {
             double s1 = 0.0, s2 = 0.0;
             for (int r = 0; r < W; ++r) s1 += TC[IDX(i, r, K)] * bE[r];
@@ -580,6 +703,7 @@ int64_t orc_solveQP_warm(int N, int M, int J, const double *V, const double *A, 
             if (a != a) pnan = 1;
             if (a > pinf) pinf = a;
         }
+        } /* !t_lapack */
         if (pnan) pinf = NAN; /* norm(p, Inf) propagates NaN */
 
         if (pinf > tolG) { /* :335-340 */
@@ -591,6 +715,20 @@ int64_t orc_solveQP_warm(int N, int M, int J, const double *V, const double *A, 
                 continue;
             }
         }
+        if (t_lapack) {
+            /* alphaL = -(TC'*c + C*bE)   :351 */
+            lp_gemv('T', K, W, -1.0, TC, K, w->c, 0.0, w->alphaL);
+            lp_gemv('N', W, W, -1.0, C, W > 0 ? W : 1, bE, 1.0, w->alphaL);
+            /* gamma = VBF*alpha + V[B,B]*zB + q[B] + AB'*alphaL   :352 (V[B,B] is gathered like the reference does) */
+            for (int k = 0; k < R; ++k) {
+                const double *col = V + (size_t)w->iB[k] * N;
+                for (int r = 0; r < R; ++r) w->VBB[IDX(r, k, R)] = col[w->iB[r]];
+                w->gamma[k] = q[w->iB[k]];
+            }
+            lp_gemv('N', R, K, 1.0, w->VBF, R > 0 ? R : 1, w->alpha, 1.0, w->gamma);
+            lp_gemv('N', R, R, 1.0, w->VBB, R > 0 ? R : 1, w->zB, 1.0, w->gamma);
+            lp_gemv('T', W, R, 1.0, AB, W > 0 ? W : 1, w->alphaL, 1.0, w->gamma);
+        } else {
         /* alphaL = -(TC'*c + C*bE)   :351 */
         for (int r = 0; r < W; ++r) {
             double s = 0.0;
@@ -609,6 +747,7 @@ int64_t orc_solveQP_warm(int N, int M, int J, const double *V, const double *A, 
             for (int r2 = 0; r2 < W; ++r2) s3 += AB[IDX(r2, r, W)] * w->alphaL[r2];
             w->gamma[r] = ((s1 + s2) + q[i]) + s3;
         }
+        } /* !t_lapack */
         /* KKTchk!   :136-188 */
         event_t *Li = w->ev;
         int nL = 0;
@@ -953,13 +1092,29 @@ int64_t orc_solveQP(int N, int M, int J, const double *V, const double *A, const
 
 /* Batch driver used by tests and by bench.py's cpu_baseline leg: problems are
  * stored back to back; one QP per OpenMP thread.  Returns threads used. */
+int orc_solveQP_warm_batch2(int nprob, int N, int M, int J, const double *V, const double *A,
+                            const double *G, const double *q, const double *b, const double *g,
+                            const double *d, const double *u, int32_t *S, const double *x0,
+                            double *z, const orc_settings *st, int64_t *status, int32_t *detail,
+                            int nthreads, int lapack);
 int orc_solveQP_warm_batch(int nprob, int N, int M, int J, const double *V, const double *A,
                            const double *G, const double *q, const double *b, const double *g,
                            const double *d, const double *u, int32_t *S, const double *x0,
                            double *z, const orc_settings *st, int64_t *status, int32_t *detail,
                            int nthreads)
 {
+    return orc_solveQP_warm_batch2(nprob, N, M, J, V, A, G, q, b, g, d, u, S, x0, z, st, status, detail, nthreads, 0);
+}
+
+/* lapack != 0: the dense arithmetic by LAPACK/BLAS (orc_lapack_load must have succeeded) */
+int orc_solveQP_warm_batch2(int nprob, int N, int M, int J, const double *V, const double *A,
+                            const double *G, const double *q, const double *b, const double *g,
+                            const double *d, const double *u, int32_t *S, const double *x0,
+                            double *z, const orc_settings *st, int64_t *status, int32_t *detail,
+                            int nthreads, int lapack)
+{
     int used = 1;
+    if (lapack && !LP.h) return -1;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
     used = nthreads > 0 ? nthreads : omp_get_max_threads();
@@ -968,11 +1123,13 @@ int orc_solveQP_warm_batch(int nprob, int N, int M, int J, const double *V, cons
     for (int p = 0; p < nprob; ++p) {
         size_t P = (size_t)p;
         int32_t det = 0;
+        t_lapack = lapack;
         status[p] = orc_solveQP_warm(N, M, J, V + P * N * N, A + P * M * N, G + P * J * N,
                                      q + P * N, b + P * M, g + P * J, d + P * N, u + P * N,
                                      S + P * (N + J), x0 + P * N, z + P * N, st, &det, NULL, 0,
                                      NULL);
         if (detail) detail[p] = det;
+        t_lapack = 0;
     }
     return used;
 }

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ssqp_hip.h"
@@ -33,7 +34,7 @@ struct ssqp_ctx {
     int optWaveKernel = 1;   // 0: never use the wavefront-per-QP kernel
     int optWaveQPC = 4;      // QPs (wavefronts) per CU of the wavefront kernel: 4..8
     // grow-only device workspaces
-    DevBuf Ct, rhs, queue, gscratch, fbList, fbIter, wscratch;
+    DevBuf Ct, rhs, queue, gscratch, fbList, fbIter, wscratch, p1ws, p1wsInt;
     // staging buffers of the host-pointer entry points
     DevBuf hV, hA, hG, hq, hb, hg, hd, hu, hS, hx0, hz, hstatus, hdetail, hstats;
 };
@@ -111,7 +112,7 @@ int ssqp_ctx_destroy(ssqp_ctx *c) {
     if (!c) return SSQP_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->Ct, &c->rhs, &c->queue, &c->gscratch, &c->fbList, &c->fbIter, &c->wscratch, &c->hV, &c->hA, &c->hG, &c->hq, &c->hb, &c->hg,
+    for (DevBuf *b : {&c->Ct, &c->rhs, &c->queue, &c->gscratch, &c->fbList, &c->fbIter, &c->wscratch, &c->p1ws, &c->p1wsInt, &c->hV, &c->hA, &c->hG, &c->hq, &c->hb, &c->hg,
                       &c->hd, &c->hu, &c->hS, &c->hx0, &c->hz, &c->hstatus, &c->hdetail, &c->hstats})
         release(*b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -352,6 +353,68 @@ int ssqp_solve_batch_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const doub
                                            c->stream), "D2H"))
         return SSQP_ERR_HIP;
     if (!hip_ok(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return SSQP_ERR_HIP;
+    return SSQP_OK;
+}
+
+int ssqp_phase1_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const double *dA, const double *dG,
+                              const double *db, const double *dg, const double *dd, const double *du,
+                              const ssqp_settings *settingsLP, double *dx0, int32_t *dS, int32_t *dstatus, void *stream) {
+    if (!c) return SSQP_ERR_ARG;
+    if (nprob < 0 || N <= 0 || M < 0 || J < 0 || !dd || !du || !dx0 || !dS || !dstatus || (M > 0 && (!dA || !db)) ||
+        (J > 0 && (!dG || !dg))) {
+        c->err = "bad argument";
+        return SSQP_ERR_ARG;
+    }
+    if (nprob == 0) return SSQP_OK;
+    ssqp_settings def;
+    ssqp_default_settings(&def);
+    const ssqp_settings *st = settingsLP ? settingsLP : &def;
+    if (st->rule != 0) {
+        c->err = "only rule = :Dantzig is implemented for Phase-1";
+        return SSQP_ERR_UNSUPPORTED;
+    }
+    if (ssqp::phase1_lds_bytes(M, J) > (size_t)ssqp::LDS_BYTES) {
+        c->err = "M + J too large for the GPU Phase-1 (the basis inverse does not fit in LDS): use ssqp_phase1_batch_f64";
+        return SSQP_ERR_UNSUPPORTED;
+    }
+    if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return SSQP_ERR_HIP;
+    const size_t wd = ssqp::phase1_ws_doubles(N, M, J), wi = ssqp::phase1_ws_ints(N, M, J);
+    if (!ensure(c, c->p1ws, (size_t)nprob * wd * 8) || !ensure(c, c->p1wsInt, (size_t)nprob * wi * 4)) return SSQP_ERR_ALLOC;
+    return hip_ok(c, ssqp::launch_phase1(nprob, N, M, J, dA, dG, db, dg, dd, du, st->tol, dx0, dS, dstatus,
+                                         (double *)c->p1ws.p, wd, (int *)c->p1wsInt.p, wi, (hipStream_t)stream),
+                  "phase-1 launch") ? SSQP_OK : SSQP_ERR_HIP;
+}
+
+int ssqp_solve_batch_multi_f64(ssqp_ctx *const *ctxs, int nctx, int nprob, int N, int M, int J, const double *V,
+                               const double *A, const double *G, const double *q, const double *b, const double *g,
+                               const double *d, const double *u, int32_t *S, const double *x0, double *z,
+                               const ssqp_settings *settings, int64_t *status, int32_t *detail, ssqp_stats *stats) {
+    if (!ctxs || nctx <= 0 || nprob < 0) return SSQP_ERR_ARG;
+    for (int k = 0; k < nctx; ++k)
+        if (!ctxs[k]) return SSQP_ERR_ARG;
+    if (nprob == 0) return SSQP_OK;
+    // contiguous blocks: context r owns problems [r*ceil(P/G), (r+1)*ceil(P/G))  (SURVEY.md section 8e); the QPs are
+    // independent, so there is no exchange between the shards -- every shard's results land in the caller's arrays
+    const int per = (nprob + nctx - 1) / nctx;
+    std::vector<int> rcs((size_t)nctx, SSQP_OK);
+    std::vector<std::thread> th;
+    const size_t n = (size_t)N, m = (size_t)M, j = (size_t)J;
+    for (int r = 0; r < nctx; ++r) {
+        const int lo = r * per < nprob ? r * per : nprob;
+        const int hi = lo + per < nprob ? lo + per : nprob;
+        if (hi <= lo) continue;
+        th.emplace_back([=, &rcs]() {
+            const size_t o = (size_t)lo;
+            rcs[(size_t)r] = ssqp_solve_batch_f64(ctxs[r], hi - lo, N, M, J, V + o * n * n, A ? A + o * m * n : nullptr,
+                                                  G ? G + o * j * n : nullptr, q + o * n, b ? b + o * m : nullptr,
+                                                  g ? g + o * j : nullptr, d + o * n, u + o * n, S + o * (n + j),
+                                                  x0 + o * n, z + o * n, settings, status + o,
+                                                  detail ? detail + o : nullptr, stats ? stats + o : nullptr);
+        });
+    }
+    for (std::thread &t : th) t.join();
+    for (int r = 0; r < nctx; ++r)
+        if (rcs[(size_t)r] != SSQP_OK) return rcs[(size_t)r];
     return SSQP_OK;
 }
 

@@ -146,5 +146,13 @@ int wave_lds_bytes(int rc);
 size_t wave_scratch_doubles(int N, int M, int J);
 hipError_t launch_solve_wave(const SolveParams &P, int grid, hipStream_t stream);
 
+// ---- Phase-1 on the GPU (ssqp_phase1.hip): one workgroup per QP
+size_t phase1_ws_doubles(int N, int M, int J);
+size_t phase1_ws_ints(int N, int M, int J);
+size_t phase1_lds_bytes(int M, int J);
+hipError_t launch_phase1(int nprob, int N, int M, int J, const double *A, const double *G, const double *b, const double *g,
+                         const double *d, const double *u, double tol, double *x0, int32_t *S, int32_t *status, double *ws,
+                         size_t wsStride, int *wsInt, size_t wsIntStride, hipStream_t stream);
+
 }  // namespace ssqp
 #endif

@@ -426,6 +426,7 @@ constexpr int CNT0 = 2 * NW + 16;  // first count slot in ired
 constexpr int EVT_MAX = 16;
 constexpr int HQ_CHANGED = 2 * NW + 8;  // ired slot: hq was updated by a status switch since the border columns were formed
 constexpr int ROWS_DIRTY = 2 * NW + 15;  // ired slot: an inequality changed status since the row lists were formed
+constexpr int SHIFT_COUNT = 2 * NW + 6;  // ired slot: status switches that updated hq / bEall by one column since their last full evaluation
 constexpr int HB_DIRTY = 2 * NW + 13;  // ired slot: a bound variable with z != 0 changed status since hq was formed
 template <int MPT>
 __device__ __forceinline__ int compact_free(const Lds &L, int N) {
@@ -1538,7 +1539,15 @@ __device__ __forceinline__ void bound_event(const Lds &L, const double *__restri
         *reinterpret_cast<double2 *>(L.hq + r) = hv;
     }
     if (tid < MJ) L.bEall[tid] = fma(-cj, dz, L.bEall[tid]);
-    if (tid == 0) L.ired[HQ_CHANGED] = 1;  // the border column L^-1 c kept from the last pass is stale
+    if (tid == 0) {
+        L.ired[HQ_CHANGED] = 1;  // the border column L^-1 c kept from the last pass is stale
+        // rounding of these one-column updates must not pile up over a long run (the reference re-evaluates
+        // VBF'zB and bE in every pass): every 64th switch asks for a full re-evaluation
+        if (++L.ired[SHIFT_COUNT] >= 64) {
+            L.ired[SHIFT_COUNT] = 0;
+            L.ired[HB_DIRTY] = 1;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ the loop
@@ -2628,6 +2637,7 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
         L.ired[ROWS_DIRTY] = 1;
         L.ired[2 * NW + 9] = 0;
         L.ired[HQ_CHANGED] = 0;
+        L.ired[SHIFT_COUNT] = 0;
     }
     if (P.incremental) {
         int rc = INC_KMAX;

@@ -1,0 +1,472 @@
+// ssqp_phase1.hip -- gfx950: Phase-1 of solveQP(Q) for a BATCH of QPs on the GPU, one 256-thread workgroup per QP.
+//
+// Replaces initQP (reference: src/SSQP.jl:461-560) and the bounded-variable simplex it calls, cDantzigLP
+// (src/Simplex.jl:445-615), as the host C++ version in ssqp_host.cpp (phase1_one / BoundedSimplex) does -- and is
+// BIT-IDENTICAL to it: the vertex (x0, S0) is what the active-set loop starts from, and the loop's pass count
+// depends on it, so every decision (largest-distance Dantzig pricing with the switch to Bland's rule after N loops,
+// first-minimum ratio test, bound flips, sorted basis, inv(lu(A[:,B])) with partial pivoting) and every rounding
+// has to be the host's.  That fixes the arithmetic: each sum runs in the host's order with separately rounded
+// multiply and add (this file is compiled with -ffp-contract=off), IEEE division and square root.  What the GPU adds is
+// width: every column of the LP (N + J + n + M0 of them) belongs to one thread -- its entries of Y = invB*A[:,k],
+// its reduced cost, its candidate ratio -- and the only sequential pieces are the ones the summation order forces
+// (the ratio test over the M0 basic rows, the pivot search of the LU, the sums over the nonbasic columns that sit
+// at a nonzero bound, taken from a compacted list).
+//
+// Workspace per QP in global memory (L2-resident: 119 KB at N = 512, M0 = 11): the LP matrix A1 (M0 x N1), Y (M0 x N1)
+// and the N1-vectors; LDS holds invB, the basis matrix being inverted and the M0-vectors.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ssqp_hip.h"
+#include "ssqp_internal.h"
+
+namespace ssqp {
+namespace p1 {
+
+constexpr int NT1 = 256;
+constexpr double INF = __builtin_huge_val();
+
+struct Ws {  // per-QP global workspace, all of length N1 unless noted
+    double *A1, *Y;  // M0 x N1, column-major
+    double *lo, *hi, *cost, *x, *colnorm, *range;
+    int32_t *S1;
+    int *nonbasic;   // 1 = nonbasic
+    int *list;       // compacted column list (N1)
+    int *freeVars;   // N
+    int *upperOnly;  // N
+};
+
+__device__ __forceinline__ size_t ws_doubles(int M0, int N1) { return (size_t)2 * M0 * N1 + 6 * (size_t)N1; }
+
+// block-wide (value, index) maximum with the FIRST maximum winning (smallest index on ties); all threads get it
+__device__ __forceinline__ void block_first_max(double &v, int &idx, double *rv, int *ri) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(idx, off);
+        const bool take = (ov > v) || (ov == v && oi < idx);
+        v = take ? ov : v;
+        idx = take ? oi : idx;
+    }
+    if (lane == 0) {
+        rv[wave] = v;
+        ri[wave] = idx;
+    }
+    __syncthreads();
+    v = rv[0];
+    idx = ri[0];
+    for (int w = 1; w < NT1 / 64; ++w) {
+        const bool take = (rv[w] > v) || (rv[w] == v && ri[w] < idx);
+        v = take ? rv[w] : v;
+        idx = take ? ri[w] : idx;
+    }
+    __syncthreads();
+}
+
+// ascending list of the columns k < n with pred(k): one wavefront scans in chunks of 64 (ballot + popcount keeps
+// the order); returns the count to every thread through *cnt (LDS)
+template <class Pred>
+__device__ __forceinline__ int compact_columns(int n, int *list, int *cnt, Pred pred) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int base = 0;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int k = c0 + lane;
+            const bool f = (k < n) && pred(k);
+            const unsigned long long m = __ballot(f);
+            if (f) list[base + __popcll(m & ((1ull << lane) - 1ull))] = k;
+            base += __popcll(m);
+        }
+        if (lane == 0) *cnt = base;
+    }
+    __syncthreads();
+    return *cnt;
+}
+
+// inv(lu(a)) in place for the n x n column-major LDS matrix a (scratch x: n x n), partial pivoting, the host's
+// operation order per element (ssqp_host.cpp invert_lu).  Returns false when a pivot is exactly 0.
+__device__ __forceinline__ bool invert_lu(double *a, double *x, int *piv, int n, int *flag) {
+    const int tid = threadIdx.x;
+    for (int k = 0; k < n; ++k) {
+        if (tid == 0) {
+            int p = k;
+            double best = fabs(a[(size_t)k * n + k]);
+            for (int i = k + 1; i < n; ++i) {
+                const double v = fabs(a[(size_t)k * n + i]);
+                if (v > best) best = v, p = i;
+            }
+            piv[k] = p;
+            *flag = (best == 0.0) ? 0 : 1;
+        }
+        __syncthreads();
+        if (!*flag) return false;
+        const int p = piv[k];
+        if (p != k)
+            for (int j = tid; j < n; j += NT1) {
+                const double t = a[(size_t)j * n + k];
+                a[(size_t)j * n + k] = a[(size_t)j * n + p];
+                a[(size_t)j * n + p] = t;
+            }
+        __syncthreads();
+        const double r = 1.0 / a[(size_t)k * n + k];
+        __syncthreads();
+        for (int i = k + 1 + tid; i < n; i += NT1) a[(size_t)k * n + i] *= r;
+        __syncthreads();
+        const int w = n - k - 1;
+        for (int e = tid; e < w * w; e += NT1) {
+            const int i = k + 1 + e % w, j = k + 1 + e / w;
+            a[(size_t)j * n + i] -= a[(size_t)k * n + i] * a[(size_t)j * n + k];
+        }
+        __syncthreads();
+    }
+    // columns of the inverse: thread c solves L U x = P e_c with the host's loops
+    for (int c = tid; c < n; c += NT1) {
+        double *xc = x + (size_t)c * n;
+        for (int i = 0; i < n; ++i) xc[i] = 0.0;
+        xc[c] = 1.0;
+        for (int k = 0; k < n; ++k)
+            if (piv[k] != k) {
+                const double t = xc[k];
+                xc[k] = xc[piv[k]];
+                xc[piv[k]] = t;
+            }
+        for (int k = 0; k < n; ++k) {
+            const double t = xc[k];
+            if (t != 0.0)
+                for (int i = k + 1; i < n; ++i) xc[i] -= a[(size_t)k * n + i] * t;
+        }
+        for (int k = n - 1; k >= 0; --k) {
+            xc[k] /= a[(size_t)k * n + k];
+            const double t = xc[k];
+            for (int i = 0; i < k; ++i) xc[i] -= a[(size_t)k * n + i] * t;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += NT1) a[e] = x[e];
+    __syncthreads();
+    return true;
+}
+
+struct P1Params {
+    int nprob, N, M, J;
+    const double *A, *G, *b, *g, *d, *u;   // per problem, back to back (A: M x N, G: J x N, column-major)
+    double tol;
+    double *x0;
+    int32_t *S;
+    int32_t *status;
+    double *ws;        // nprob workspaces of wsStride doubles
+    size_t wsStride;
+    int *wsInt;        // nprob integer workspaces of wsIntStride ints
+    size_t wsIntStride;
+};
+
+__global__ __launch_bounds__(NT1) void ssqp_phase1_kernel(P1Params P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int prob = blockIdx.x;
+    if (prob >= P.nprob) return;
+    const int tid = threadIdx.x;
+    const int N = P.N, M = P.M, J = P.J, M0 = M + J;
+    const double *A = P.A + (size_t)prob * M * N;
+    const double *G = P.G + (size_t)prob * J * N;
+    const double *b = P.b + (size_t)prob * M;
+    const double *g = P.g + (size_t)prob * J;
+    const double *d = P.d + (size_t)prob * N;
+    const double *u = P.u + (size_t)prob * N;
+    const double tol = P.tol;
+    double *x0 = P.x0 + (size_t)prob * N;
+    int32_t *S = P.S + (size_t)prob * (N + J);
+
+    // ---- LDS: invB, Bm (M0 x M0 each), rhs, xb, pvec, start (M0 each), small integers
+    double *invB = reinterpret_cast<double *>(smem);
+    double *Bm = invB + (size_t)M0 * M0;
+    double *rhs = Bm + (size_t)M0 * M0;
+    double *xb = rhs + M0;
+    double *pv = xb + M0;
+    double *acc = pv + M0;
+    double *redv = acc + M0;                       // 4
+    int *basis = reinterpret_cast<int *>(redv + 4);  // M0
+    int *piv = basis + M0;                         // M0
+    int *redi = piv + M0;                          // 4
+    int *misc = redi + 4;                          // [0] count, [1] flag, [2] action, [3] leaveStatus, [4] n free, [5] n upperOnly
+
+    // ---- free / upper-only variables (SSQP.jl:484-509), ascending lists
+    int *iw = P.wsInt + (size_t)prob * P.wsIntStride;
+    int *freeVars = iw, *upperOnly = iw + N;
+    const int nfree = compact_columns(N, freeVars, &misc[4], [&](int k) { return u[k] == INF && d[k] == -INF; });
+    const int nup = compact_columns(N, upperOnly, &misc[5], [&](int k) { return !(u[k] == INF && d[k] == -INF) && d[k] == -INF; });
+    const int N0 = N + J + nfree, N1 = N0 + M0;
+    int32_t *S1 = iw + 2 * N;
+    int *nonbasic = S1 + N1;
+    int *list = nonbasic + N1;
+    double *wd = P.ws + (size_t)prob * P.wsStride;
+    double *A1 = wd;
+    double *Y = A1 + (size_t)M0 * N1;
+    double *lo = Y + (size_t)M0 * N1;
+    double *hi = lo + N1, *cost = hi + N1, *x = cost + N1, *colnorm = x + N1, *range = colnorm + N1;
+
+    // ---- the LP of initQP: A1 = [A; G | slack | -free copies | artificials]
+    for (size_t e = tid; e < (size_t)M0 * N1; e += NT1) A1[e] = 0.0;
+    for (int k = tid; k < N1; k += NT1) {
+        lo[k] = 0.0;
+        hi[k] = INF;
+        cost[k] = 0.0;
+        S1[k] = SSQP_DN;
+    }
+    __syncthreads();
+    for (int k = tid; k < N; k += NT1) {
+        for (int r = 0; r < M; ++r) A1[(size_t)k * M0 + r] = A[(size_t)k * M + r];
+        for (int r = 0; r < J; ++r) A1[(size_t)k * M0 + M + r] = G[(size_t)k * J + r];
+        lo[k] = d[k];
+        hi[k] = u[k];
+    }
+    for (int j = tid; j < J; j += NT1) A1[(size_t)(N + j) * M0 + M + j] = 1.0;
+    __syncthreads();
+    for (int t = tid; t < nfree; t += NT1) {
+        const int k = freeVars[t];
+        for (int r = 0; r < M0; ++r) A1[(size_t)(N + J + t) * M0 + r] = -A1[(size_t)k * M0 + r];
+        lo[k] = 0.0;
+    }
+    for (int t = tid; t < nup; t += NT1) {
+        const int k = upperOnly[t];
+        lo[k] = -hi[k];
+        hi[k] = INF;
+        for (int r = 0; r < M0; ++r) A1[(size_t)k * M0 + r] = -A1[(size_t)k * M0 + r];
+    }
+    for (int r = tid; r < M0; r += NT1) rhs[r] = (r < M) ? b[r] : g[r - M];
+    __syncthreads();
+    // start = sum over the columns with lo != 0, ascending, of A1[:,k] * lo[k]
+    {
+        const int cnt = compact_columns(N0, list, &misc[0], [&](int k) { return lo[k] != 0.0; });
+        for (int r = tid; r < M0; r += NT1) {
+            double s = 0.0;
+            for (int t = 0; t < cnt; ++t) {
+                const int k = list[t];
+                s += A1[(size_t)k * M0 + r] * lo[k];
+            }
+            acc[r] = s;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < M0 * M0; e += NT1) invB[e] = 0.0;
+    __syncthreads();
+    for (int j = tid; j < M0; j += NT1) {
+        const double sgn = rhs[j] >= acc[j] ? 1.0 : -1.0;
+        invB[(size_t)j * M0 + j] = sgn;
+        A1[(size_t)(N0 + j) * M0 + j] = sgn;
+        xb[j] = fabs(acc[j] - rhs[j]);
+        basis[j] = N0 + j;
+        S1[N0 + j] = SSQP_IN;
+        cost[N0 + j] = 1.0;
+    }
+    __syncthreads();
+
+    // ---- BoundedSimplex::run
+    for (int k = tid; k < N1; k += NT1) {
+        nonbasic[k] = (k >= N0) ? 0 : 1;
+        range[k] = hi[k] - lo[k];
+        double s = 0.0;
+        for (int r = 0; r < M0; ++r) s += A1[(size_t)k * M0 + r] * A1[(size_t)k * M0 + r];
+        colnorm[k] = sqrt(s);
+        x[k] = S1[k] == SSQP_UP ? hi[k] : lo[k];
+    }
+    __syncthreads();
+    auto refreshY = [&]() {  // Y[:,k] = invB * A1[:,k] for the nonbasic columns
+        for (int k = tid; k < N1; k += NT1) {
+            if (!nonbasic[k]) continue;
+            const double *ak = A1 + (size_t)k * M0;
+            for (int r = 0; r < M0; ++r) {
+                double s = 0.0;
+                for (int t = 0; t < M0; ++t) s += invB[(size_t)t * M0 + r] * ak[t];
+                Y[(size_t)k * M0 + r] = s;
+            }
+        }
+        __syncthreads();
+    };
+    refreshY();
+    int status = 1;
+    long loop = 0;
+    for (;;) {
+        // price: signed reduced costs; the entering candidate
+        loop += 1;
+        const bool bland = loop > N1;
+        double best = -INF;
+        int bidx = 0x7fffffff;
+        for (int k = tid; k < N1; k += NT1) {
+            if (!nonbasic[k]) continue;
+            double s = 0.0;
+            for (int r = 0; r < M0; ++r) s += Y[(size_t)k * M0 + r] * cost[basis[r]];
+            double hv = cost[k] - s;
+            if (S1[k] == SSQP_DN) hv = -hv;
+            if (hv > tol) {
+                const double v = bland ? 0.0 : hv / colnorm[k];
+                if (v > best || (v == best && k < bidx)) best = v, bidx = k;  // (per thread: ascending k, first max)
+            }
+        }
+        block_first_max(best, bidx, redv, redi);
+        if (bidx == 0x7fffffff) break;  // no improving candidate: optimal
+        const int k = bidx;
+        const double *ak = A1 + (size_t)k * M0;
+        for (int r = tid; r < M0; r += NT1) {
+            double s = 0.0;
+            for (int t = 0; t < M0; ++t) s += invB[(size_t)t * M0 + r] * ak[t];
+            pv[r] = s;
+        }
+        __syncthreads();
+        if (tid == 0) {  // ratio test (first minimum / first maximum over the basic rows, in row order)
+            const bool fromLower = S1[k] == SSQP_DN;
+            int m = 0, li = -1;
+            double lr = 0.0;
+            int lrow = 0, lto = SSQP_DN;
+            for (int j = 0; j < M0; ++j) {
+                const int i = basis[j];
+                const bool pos = pv[j] > tol, neg = pv[j] < -tol;
+                if (!pos && !neg) continue;
+                const bool toLower = fromLower ? pos : neg;
+                const double ratio = (xb[j] - (toLower ? lo[i] : hi[i])) / pv[j];
+                const bool better = (m == 0) || (fromLower ? (ratio < lr) : (ratio > lr));
+                if (better) lr = ratio, li = m, lrow = j, lto = toLower ? SSQP_DN : SSQP_UP;
+                ++m;
+            }
+            int action = 0, leaveStatus = SSQP_DN, st = 0;  // st: 3 = unbounded
+            if (fromLower) {
+                const bool finiteUp = hi[k] < INF;
+                if (m == 0) {
+                    if (!finiteUp) st = 3;
+                    else action = -1;
+                } else {
+                    if (finiteUp && lr >= range[k]) action = -1;
+                    else {
+                        if (!finiteUp && isinf(lr)) st = 3;
+                        else action = lrow + 1, leaveStatus = lto;
+                    }
+                }
+            } else {
+                if (m == 0) action = -2;
+                else if (lr <= -range[k]) action = -2;
+                else action = lrow + 1, leaveStatus = lto;
+            }
+            (void)li;
+            misc[2] = action;
+            misc[3] = leaveStatus;
+            misc[1] = st;
+        }
+        __syncthreads();
+        if (misc[1] == 3) {
+            status = 3;
+            break;
+        }
+        const int action = misc[2];
+        if (action == -1) {
+            if (tid == 0) S1[k] = SSQP_UP, x[k] = hi[k];
+        } else if (action == -2) {
+            if (tid == 0) S1[k] = SSQP_DN, x[k] = lo[k];
+        } else {
+            if (tid == 0) {
+                const int leaving = basis[action - 1];
+                misc[6] = leaving;
+                nonbasic[k] = 0;
+                nonbasic[leaving] = 1;
+                basis[action - 1] = k;
+                for (int a2 = 1; a2 < M0; ++a2) {  // sort(basis)
+                    const int v = basis[a2];
+                    int c2 = a2 - 1;
+                    while (c2 >= 0 && basis[c2] > v) {
+                        basis[c2 + 1] = basis[c2];
+                        --c2;
+                    }
+                    basis[c2 + 1] = v;
+                }
+            }
+            __syncthreads();
+            for (int e = tid; e < M0 * M0; e += NT1) invB[e] = A1[(size_t)basis[e / M0] * M0 + e % M0];
+            __syncthreads();
+            if (!invert_lu(invB, Bm, piv, M0, &misc[1])) {  // lu() of the reference throws (Simplex.jl:590)
+                status = -1;
+                break;
+            }
+            if (tid == 0) {
+                const int leaving = misc[6], leaveStatus = misc[3];
+                S1[k] = SSQP_IN;
+                S1[leaving] = leaveStatus;
+                x[leaving] = leaveStatus == SSQP_DN ? lo[leaving] : hi[leaving];
+            }
+            refreshY();
+        }
+        __syncthreads();
+        // xb = invB*b - Y*x[nonbasic]: the nonbasic columns at a nonzero value, ascending
+        {
+            const int cnt = compact_columns(N1, list, &misc[0], [&](int kk) { return nonbasic[kk] && x[kk] != 0.0; });
+            for (int r = tid; r < M0; r += NT1) {
+                double a2 = 0.0;
+                for (int t = 0; t < cnt; ++t) {
+                    const int kk = list[t];
+                    a2 += Y[(size_t)kk * M0 + r] * x[kk];
+                }
+                double s = 0.0;
+                for (int t = 0; t < M0; ++t) s += invB[(size_t)t * M0 + r] * rhs[t];
+                xb[r] = s - a2;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // ---- finish(): values of the basic variables; then initQP's mapping back (SSQP.jl:533-557)
+    if (status >= 0)
+        for (int j = tid; j < M0; j += NT1) x[basis[j]] = xb[j];
+    __syncthreads();
+    for (int k = tid; k < N; k += NT1) x0[k] = x[k];
+    for (int k = tid; k < N + J; k += NT1) S[k] = S1[k];
+    __syncthreads();
+    if (status < 0) {
+        if (tid == 0) P.status[prob] = -1;
+        return;
+    }
+    if (tid == 0) {
+        double art = 0.0;
+        for (int k = N0; k < N1; ++k) art += x[k];
+        misc[0] = (art > tol) ? 0 : 1;
+        P.status[prob] = misc[0];
+    }
+    __syncthreads();
+    if (misc[0] == 0) return;
+    for (int k = N + tid; k < N + J; k += NT1) S[k] = (S1[k] == SSQP_IN) ? SSQP_OE : SSQP_EO;
+    for (int t = tid; t < nfree; t += NT1) {
+        x0[freeVars[t]] = x[freeVars[t]] - x[N + J + t];
+        S[freeVars[t]] = SSQP_IN;
+    }
+    __syncthreads();
+    for (int t = tid; t < nup; t += NT1) x0[upperOnly[t]] = -x0[upperOnly[t]];  // (statuses stay: SSQP.jl:552-557 is a no-op)
+}
+
+}  // namespace p1
+
+size_t phase1_ws_doubles(int N, int M, int J) {
+    const int M0 = M + J, N1 = 2 * N + J + M0;  // (every variable free: n = N)
+    return (size_t)2 * M0 * N1 + 6 * (size_t)N1 + 8;
+}
+size_t phase1_ws_ints(int N, int M, int J) {
+    const int M0 = M + J, N1 = 2 * N + J + M0;
+    return (size_t)2 * N + 3 * (size_t)N1 + 8;
+}
+size_t phase1_lds_bytes(int M, int J) {
+    const size_t M0 = (size_t)(M + J);
+    return (2 * M0 * M0 + 4 * M0 + 4) * 8 + (2 * M0 + 4 + 8) * 4 + 64;
+}
+hipError_t launch_phase1(int nprob, int N, int M, int J, const double *A, const double *G, const double *b, const double *g,
+                         const double *d, const double *u, double tol, double *x0, int32_t *S, int32_t *status, double *ws,
+                         size_t wsStride, int *wsInt, size_t wsIntStride, hipStream_t stream) {
+    p1::P1Params P;
+    P.nprob = nprob; P.N = N; P.M = M; P.J = J;
+    P.A = A; P.G = G; P.b = b; P.g = g; P.d = d; P.u = u;
+    P.tol = tol;
+    P.x0 = x0; P.S = S; P.status = status;
+    P.ws = ws; P.wsStride = wsStride; P.wsInt = wsInt; P.wsIntStride = wsIntStride;
+    const size_t lds = phase1_lds_bytes(M, J);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&p1::ssqp_phase1_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(p1::ssqp_phase1_kernel, dim3(nprob), dim3(p1::NT1), lds, stream, P);
+    return hipGetLastError();
+}
+
+}  // namespace ssqp

@@ -861,6 +861,7 @@ struct WState {
     unsigned Emask;     // active inequalities (bit j: S[N+j] == EO)
     double bEv;         // lane w: bEall_w = rhs_w - ([A;G] zB)_w
     int K;
+    int nShift;         // status switches since hq / bEall were last re-evaluated from (z, S)
     bool hbValid, cDirty;
     // pending changes of F decided by the last pass
     unsigned long long del0, del1;  // rows to delete (slot 0 / slot 1 lanes)
@@ -1041,6 +1042,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
                     dense_set(S.zd, jv, zn);
                     if (zn != 0.0) {
                         bound_shift(C, S.hq, S.bEv, jv, zn);
+                        S.nShift += 1;
                         S.cDirty = true;
                         C.sRead += 8ll * N + 64ll * MJ;
                     }
@@ -1228,6 +1230,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
             const double zr = dense_get(S.zd, jv);
             if (zr != 0.0) {  // B loses a column with a nonzero weight
                 bound_shift(C, S.hq, S.bEv, jv, -zr);
+                S.nShift += 1;
                 S.cDirty = true;
                 C.sRead += 8ll * N + 64ll * MJ;
             }
@@ -1440,6 +1443,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     S.K = 0;
     S.hbValid = false;
     S.cDirty = false;
+    S.nShift = 0;
     S.del0 = S.del1 = 0ull;
     S.appJ = -1;
     S.appAll = true;
@@ -1455,7 +1459,11 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
             break;
         }
         ssqp_trace *trace = (C.trace && C.iter <= C.ntrace) ? C.trace + (C.iter - 1) : nullptr;
+        // hq and bEall follow the status switches by one column each; rounding of those updates must not pile up
+        // over a long run (the reference re-evaluates VBF'zB and bE in every pass): re-evaluate every 64 switches
+        if (S.nShift >= 64) S.hbValid = false;
         if (!S.hbValid) {
+            S.nShift = 0;
             refresh_caches(C, S.hq, S.bEv, S.zd, S.Sp);
             S.hbValid = true;
             S.cDirty = true;

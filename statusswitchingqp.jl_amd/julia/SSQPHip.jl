@@ -1,19 +1,27 @@
 # SSQPHip.jl -- Julia side of the drop-in boundary (UNVERIFIED: no Julia in the build image or on the GPU box).
 #
-# Adds GPU methods for the two reference entry points of the hot path and leaves everything else
-# (QP/LP types, Settings, MOI wrapper, LP solvers) to StatusSwitchingQP.jl itself:
+# EXTENDS the reference's own generic function: after `using SSQPHip`, the more specific Float64 method below is
+# what `StatusSwitchingQP.solveQP(Q, S, x0; settings)` dispatches to, so every caller of the reference reaches
+# the GPU unchanged:
 #
-#   solveQP(Q::QP{Float64}, S, x0; settings)      replaces src/SSQP.jl:237-377
-#   solveQP(Q::QP{Float64}; settings, settingsLP) replaces src/SSQP.jl:224-234
+#   solveQP(Q::QP{Float64}, S, x0; settings)        replaces src/SSQP.jl:237-377  (the hot path)
+#   solveQP(Q::QP{Float64}; settings, settingsLP)   src/SSQP.jl:224-234 keeps running the reference's own initQP
+#                                                   (Phase-1) and then calls the 3-argument method (:233) -> GPU
+#   MOI.optimize!(::Optimizer)                      src/MOIwrapper.jl:165 calls solveQP(opt.Problem; ...) -> GPU
 #
-# Usage:  ENV["SSQP_HIP_LIB"] = "/path/to/libssqp_hip.so"; include("SSQPHip.jl"); using .SSQPHip
-#         z, S, status = SSQPHip.solveQP(Q)          # same return triple as the reference
+# Everything else (QP/LP types, Settings, LP solvers, the MOI wrapper) stays the reference's.  BigFloat problems
+# keep the reference's CPU method (the method below is for Float64 only).
+#
+# Usage:  ENV["SSQP_HIP_LIB"] = "/path/to/libssqp_hip.so"; using StatusSwitchingQP; include("SSQPHip.jl"); using .SSQPHip
+#         z, S, status = solveQP(Q)        # the reference's entry point, same return triple
 module SSQPHip
 
+using LinearAlgebra
 using StatusSwitchingQP
+import StatusSwitchingQP: solveQP                     # methods are ADDED to the reference's function
 using StatusSwitchingQP: QP, Settings, Status, DN
 
-export solveQP
+export solveQP, solveQP_batch, solveQP_full_hip, use_moi_qp_status!
 
 const libssqp = get(ENV, "SSQP_HIP_LIB", "libssqp_hip.so")
 
@@ -29,26 +37,30 @@ function CSettings(s::Settings{Float64})
     CSettings(Int32(s.maxIter), Int32(0), s.tol, s.tolG)
 end
 
-const _ctx = Ref{Ptr{Cvoid}}(C_NULL)
-function ctx()
-    if _ctx[] == C_NULL
-        rc = ccall((:ssqp_ctx_create, libssqp), Cint, (Cint, Ref{Ptr{Cvoid}}), 0, _ctx)
-        rc == 0 || error("ssqp_ctx_create failed with code $rc (2 = no HIP device; there is no CPU fallback)")
+# one context per GPU (ssqp_ctx_create(dev, ...)); created on first use
+const _ctxs = Dict{Int,Ptr{Cvoid}}()
+function ctx(dev::Integer=0)
+    get!(_ctxs, Int(dev)) do
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:ssqp_ctx_create, libssqp), Cint, (Cint, Ref{Ptr{Cvoid}}), dev, r)
+        rc == 0 || error("ssqp_ctx_create($dev) failed with code $rc (2 = no HIP device; there is no CPU fallback)")
+        r[]
     end
-    _ctx[]
 end
 
-check(rc) = rc == 0 || error("libssqp_hip: code $rc: " *
-    unsafe_string(ccall((:ssqp_last_error, libssqp), Cstring, (Ptr{Cvoid},), _ctx[])))
+check(rc, c=ctx()) = rc == 0 || error("libssqp_hip: code $rc: " *
+    unsafe_string(ccall((:ssqp_last_error, libssqp), Cstring, (Ptr{Cvoid},), c)))
 
 # detail codes: 1/2 = a cholesky in the loop would have thrown, 3 = lu in Phase-1 would have thrown
 rethrow_detail(detail) = detail in (1, 2) ? throw(LinearAlgebra.PosDefException(detail)) :
                          detail == 3 ? throw(LinearAlgebra.SingularException(0)) : nothing
 
 """
-    solveQP(Q::QP{Float64}, S::Vector{Status}, x0; settings=Settings{Float64}())
+    solveQP(Q::QP{Float64}, S::Vector{Status}, x0::Vector{Float64}; settings=Settings{Float64}())
 
-The hot path on the GPU.  `S` is mutated in place and returned, `x0` is not modified (SSQP.jl:264-266).
+The hot path on the GPU (a method of `StatusSwitchingQP.solveQP`).  `S` is mutated in place and returned, `x0` is
+not modified (SSQP.jl:264-266).  `throw_like_reference=true` rethrows the LAPACK exception the reference would have
+raised where the library returns `status = -1` with a detail code.
 """
 function solveQP(Q::QP{Float64}, S::Vector{Status}, x0::Vector{Float64}; settings=Settings{Float64}(),
                  throw_like_reference::Bool=false)
@@ -70,11 +82,14 @@ function solveQP(Q::QP{Float64}, S::Vector{Status}, x0::Vector{Float64}; setting
 end
 
 """
-    solveQP(Q::QP{Float64}; settings=Settings{Float64}(), settingsLP=settings)
+    solveQP_full_hip(Q::QP{Float64}; settings, settingsLP)
 
-Phase-1 (initQP) on the host inside the library, then the GPU loop.
+`solveQP(Q)` with Phase-1 ALSO inside the library (its C++ restatement of initQP, SSQP.jl:461-560) instead of the
+reference's Julia initQP.  Not installed as a method of `solveQP`: the reference's own one-argument method already
+reaches the GPU through the three-argument method above.
 """
-function solveQP(Q::QP{Float64}; settings=Settings{Float64}(), settingsLP=settings, throw_like_reference::Bool=false)
+function solveQP_full_hip(Q::QP{Float64}; settings=Settings{Float64}(), settingsLP=settings,
+                          throw_like_reference::Bool=false)
     if Q.mc <= 0
         return zeros(Float64, Q.N), fill(DN, Q.N), -1          # SSQP.jl:226-228
     end
@@ -96,7 +111,67 @@ function solveQP(Q::QP{Float64}; settings=Settings{Float64}(), settingsLP=settin
     return z, S, Int(status[])
 end
 
-# BigFloat (and any T != Float64) stays on the reference's CPU path
-solveQP(Q::QP, args...; kwargs...) = StatusSwitchingQP.solveQP(Q, args...; kwargs...)
+"""
+    solveQP_batch(Qs::Vector{QP{Float64}}, Ss, x0s; settings, gpus=[0])
+
+A batch of equal-shape QPs in ONE call, cut into contiguous blocks over the listed GPUs
+(`ssqp_solve_batch_multi_f64`: one context and one host thread per GPU, no exchange between the blocks; the
+results of every block land in the arrays returned here).  `Ss[p]` is mutated in place like in `solveQP`.
+"""
+function solveQP_batch(Qs::Vector{QP{Float64}}, Ss::Vector{Vector{Status}}, x0s::Vector{Vector{Float64}};
+                       settings=Settings{Float64}(), gpus=[0])
+    P = length(Qs)
+    P == 0 && return Vector{Float64}[], Ss, Int[]
+    N, M, J = Qs[1].N, Qs[1].M, Qs[1].J
+    all(q -> (q.N, q.M, q.J) == (N, M, J), Qs) || throw(DimensionMismatch("solveQP_batch needs equal shapes"))
+    pack(f, len) = (a = Vector{Float64}(undef, len * P); for p in 1:P; copyto!(a, (p - 1) * len + 1, vec(f(Qs[p])), 1, len); end; a)
+    V = pack(q -> q.V, N * N); A = pack(q -> q.A, M * N); G = pack(q -> q.G, J * N)
+    qv = pack(q -> q.q, N); b = pack(q -> q.b, M); g = pack(q -> q.g, J); d = pack(q -> q.d, N); u = pack(q -> q.u, N)
+    S = Vector{Int32}(undef, (N + J) * P)
+    x0 = Vector{Float64}(undef, N * P)
+    for p in 1:P
+        copyto!(S, (p - 1) * (N + J) + 1, reinterpret(Int32, Ss[p]), 1, N + J)
+        copyto!(x0, (p - 1) * N + 1, x0s[p], 1, N)
+    end
+    z = Vector{Float64}(undef, N * P)
+    status = Vector{Int64}(undef, P)
+    detail = Vector{Int32}(undef, P)
+    cs = Ref(CSettings(settings))
+    cx = [ctx(dv) for dv in gpus]
+    check(ccall((:ssqp_solve_batch_multi_f64, libssqp), Cint,
+        (Ptr{Ptr{Cvoid}}, Cint, Cint, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64},
+         Ref{CSettings}, Ptr{Int64}, Ptr{Int32}, Ptr{Cvoid}),
+        cx, length(cx), P, N, M, J, V, A, G, qv, b, g, d, u, S, x0, z, cs, status, detail, C_NULL), cx[1])
+    for p in 1:P
+        copyto!(reinterpret(Int32, Ss[p]), 1, S, (p - 1) * (N + J) + 1, N + J)
+    end
+    return [z[(p - 1) * N + 1:p * N] for p in 1:P], Ss, Int.(status)
+end
+
+"""
+    use_moi_qp_status!()
+
+DELIBERATE DEVIATION, opt-in.  `MOI.get(::Optimizer, ::MOI.TerminationStatus)` of the reference maps `Results[3]`
+with the LP code table (MOIwrapper.jl:213-228), but for a QP `Results[3]` is the loop's pass count
+(MOIwrapper.jl:165, SSQP.jl:374): a QP that converges in 3 passes is reported INFEASIBLE_OR_UNBOUNDED, in 4 or more
+ITERATION_LIMIT.  This installs a method that reports `status > 0` as OPTIMAL when the stored problem is a QP and
+otherwise defers to the reference's table.
+"""
+function use_moi_qp_status!()
+    @eval begin
+        import MathOptInterface as MOI
+        function MOI.get(opt::StatusSwitchingQP.Optimizer, ::MOI.TerminationStatus)
+            opt.Results === nothing && return MOI.OPTIMIZE_NOT_CALLED
+            st = opt.Results[3]
+            if opt.Problem isa StatusSwitchingQP.QP
+                return st > 0 ? MOI.OPTIMAL : st == 0 ? MOI.INFEASIBLE : st == -1 ? MOI.NUMERICAL_ERROR : MOI.ITERATION_LIMIT
+            end
+            return st == 3 ? MOI.INFEASIBLE_OR_UNBOUNDED : st in (1, 2) ? MOI.OPTIMAL : st == 0 ? MOI.INFEASIBLE :
+                   st == -1 ? MOI.NUMERICAL_ERROR : MOI.ITERATION_LIMIT
+        end
+    end
+    nothing
+end
 
 end # module

@@ -219,6 +219,24 @@ def solveQP_batch(prob, S, x0, settings=None, ctx=None, want_stats=False):
     return z, S, status, detail
 
 
+def solveQP_batch_multi(prob, S, x0, ctxs, settings=None):
+    """The batch cut into contiguous blocks over several contexts (one per GPU; ssqp_solve_batch_multi_f64)."""
+    P, N = prob["q"].shape
+    M, J = prob["b"].shape[1], prob["g"].shape[1]
+    arrs = [_f64(prob[k]) for k in "VAGqbgdu"]
+    S = np.ascontiguousarray(S, dtype=np.int32).copy()
+    x0 = _f64(x0)
+    z = np.zeros((P, N))
+    status = np.zeros(P, dtype=np.int64)
+    detail = np.zeros(P, dtype=np.int32)
+    cs = _csettings(settings)
+    hs = (C.c_void_p * len(ctxs))(*[c.handle for c in ctxs])
+    rc = _capi.lib().ssqp_solve_batch_multi_f64(hs, len(ctxs), P, N, M, J, *[_p(a) for a in arrs], _p(S), _p(x0),
+                                                _p(z), C.byref(cs), _p(status), _p(detail), None)
+    _capi.check(rc, ctxs[0].handle)
+    return z, S, status, detail
+
+
 STATS_DTYPE = np.dtype([("iters", "<i8"), ("alg_bytes", "<i8"), ("read_bytes", "<i8"), ("alg_flops", "<i8"),
                         ("sum_k3", "<i8"),
                         ("max_k", "<i4"), ("path", "<i4")])
@@ -321,6 +339,25 @@ class DeviceBatch:
             self._ptr(self.detail), self._ptr(self.stats), self._ptr(self.trace) if self.ntrace else None,
             self.ntrace, C.c_void_p(stream))
         _capi.check(rc, self.ctx.handle)
+
+    def phase1(self, settingsLP=None, stream=None):
+        """initQP for the whole batch ON the GPU (ssqp_phase1_batch_dev_f64): fills self.x0 / self.S0 in place
+        (asynchronous) and returns the status tensor (1 feasible, 0 infeasible, -1 singular basis)."""
+        torch = self.torch
+        cs = _csettings(settingsLP)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.S.device).cuda_stream
+        if not hasattr(self, "p1status"):
+            self.p1status = torch.zeros(self.P, dtype=torch.int32, device=self.S.device)
+        t = self.t
+        for k in "AGbgdu":
+            if t[k].shape[0] == 1 and self.P > 1:
+                raise SSQPError("DeviceBatch.phase1 needs per-problem arrays (no stride-0 sharing)")
+        rc = _capi.lib().ssqp_phase1_batch_dev_f64(
+            self.ctx.handle, self.P, self.N, self.M, self.J, *[self._ptr(t[k]) for k in "AGbgdu"], C.byref(cs),
+            self._ptr(self.x0), self._ptr(self.S0), self._ptr(self.p1status), C.c_void_p(stream))
+        _capi.check(rc, self.ctx.handle)
+        return self.p1status
 
     def results(self):
         self.torch.cuda.synchronize(self.S.device)

@@ -60,3 +60,51 @@ def test_shard_range_partitions_everything():
                 assert 0 <= lo <= hi <= nprob
                 got += list(range(lo, hi))
             assert got == list(range(nprob))
+
+
+def _worker_real(rank, world, port, nprob, out):
+    """every rank solves ITS shard (the CPU oracle stands in for the GPU solve: no GPU in this test) and the results
+    are gathered exactly as bench.py does after DeviceBatch.solve()"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    from oracle import oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = pkg.GenConfig(24, 1, 2, 48, 1e-3, 0.2, 1.05, 0.1)
+    per = -(-nprob // world)
+    lo, hi = pkg.dist.shard_range(nprob, world, rank)
+    prob = pkg.generate_batch(cfg, per, pkg.BASE_SEED + rank * per)     # rank r owns seeds [r*per, (r+1)*per)
+    x0, S0, st = pkg.phase1_batch(prob)
+    z, S, status, _, _ = orc.solveQP_warm_batch(*[prob[k] for k in "VAGqbgdu"], S0, x0, nthreads=1)
+    gz, gS, gst = pkg.dist.gather_results(torch.from_numpy(z), torch.from_numpy(S), torch.from_numpy(status),
+                                          nprob_total=nprob)
+    if rank == 0:
+        np.savez(out, z=gz.numpy(), S=gS.numpy(), status=gst.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_solve_and_gather_equals_unsharded(tmp_path):
+    import socket
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    from oracle import oracle as orc
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    nprob = 7
+    out = str(tmp_path / "r.npz")
+    mp.spawn(_worker_real, args=(2, port, nprob, out), nprocs=2, join=True)
+    r = np.load(out)
+    cfg = pkg.GenConfig(24, 1, 2, 48, 1e-3, 0.2, 1.05, 0.1)
+    prob = pkg.generate_batch(cfg, 8, pkg.BASE_SEED)                     # the same seeds, one process
+    x0, S0, st = pkg.phase1_batch(prob)
+    z, S, status, _, _ = orc.solveQP_warm_batch(*[prob[k] for k in "VAGqbgdu"], S0, x0, nthreads=1)
+    assert np.array_equal(r["status"], status[:nprob]) and np.array_equal(r["S"], S[:nprob])
+    assert np.array_equal(r["z"], z[:nprob])

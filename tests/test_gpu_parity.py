@@ -169,7 +169,7 @@ def test_full_batch_properties_cfg4(pkg, orc):
     sub = {k: v[sel] for k, v in prob.items()}
     zo, So, sto, _, _ = oracle_batch(orc, sub, S0[sel], x0[sel])
     assert_parity(z[sel], S[sel], status[sel], zo, So, sto)
-    for p in sel[:8]:
+    for p in range(1024):   # independent of the restatement: every one of the 1024 solutions is a KKT point
         assert_kkt(prob["V"][p], colmajor(prob["A"][p], cfg.M), colmajor(prob["G"][p], cfg.J), prob["q"][p],
                    prob["b"][p], prob["g"][p], prob["d"][p], prob["u"][p], z[p], S[p])
     # idempotence: warm start at the optimum leaves S unchanged and stops after one pass
@@ -277,6 +277,13 @@ def _check_shapes(pkg, orc, kind, rng, shapes, nper, need):
         fin = np.isfinite(zo).all(axis=1) & conv
         scale = np.maximum(np.abs(zo[fin]).max(axis=1), 1e-300)
         assert (np.abs(z[fin] - zo[fin]).max(axis=1) / scale).max() < 1e-10 if fin.any() else True
+        # the check that shares nothing with the restatement: every converged solution satisfies the KKT conditions
+        # (a strictly convex QP has one optimum).  Free variables without bounds are skipped by the verifier's
+        # bound tests automatically (+-Inf bounds).
+        from kkt import assert_kkt
+        for p in np.flatnonzero(fin):
+            assert_kkt(sub["V"][p], colmajor(sub["A"][p], M), colmajor(sub["G"][p], J), sub["q"][p], sub["b"][p],
+                       sub["g"][p], sub["d"][p], sub["u"][p], z[p], S[p], eps=2e-7)
         total += int(conv.sum())
     assert total > need
 
@@ -328,3 +335,115 @@ def test_launch_lanes_overlap_and_agree(pkg, orc):
     full["V"] = b0.t["V"].cpu().numpy()
     zo, So, sto, _, _ = oracle_batch(orc, full, S0, x0)
     assert_parity(ref["z"], ref["S"], ref["status"], zo, So, sto)
+
+
+# ---------------------------------------------------------------- paths no BASELINE config reaches by itself
+def _oracle_fast(orc, prob, S0, x0):
+    """the oracle with LAPACK arithmetic when scipy's OpenBLAS can be bound (large K: the port's loops take minutes)"""
+    return orc.solveQP_warm_batch(prob["V"], prob["A"], prob["G"], prob["q"], prob["b"], prob["g"], prob["d"],
+                                  prob["u"], S0, x0, lapack=orc.lapack_available())
+
+
+def test_free_set_beyond_256_rows(pkg, orc):
+    """V ~ I/2 without upper bounds: nearly every variable ends up free, K grows past the 256 rows the kept factor
+    holds -- the workgroup kernel's from-scratch / global-arena / MFMA-panel path as the PRODUCT path, reached
+    through the hand-over chain wavefront kernel -> kept factor in LDS -> global arena -> from scratch."""
+    cfg = pkg.GenConfig(320, 1, 4, 640, 0.5, 0.0, 1.05, 0.0)
+    prob = pkg.generate_batch(cfg, 4, 90210)
+    x0, S0, st = pkg.phase1_batch(prob)
+    assert (st == 1).all()
+    zo, So, sto, _, _ = _oracle_fast(orc, prob, S0, x0)
+    assert (sto > 0).all()
+    ctx = pkg.default_context()
+    for opts in (dict(), dict(wave_kernel=0)):
+        with ctx.options(**opts):
+            z, S, status, detail, stats = pkg.solveQP_batch(prob, S0, x0, want_stats=True)
+        assert_parity(z, S, status, zo, So, sto)
+        assert stats["max_k"].min() > 256, stats["max_k"]
+        assert ((stats["path"] & 2) != 0).all()                  # the global arena was used
+        assert ((stats["path"] & 8) != 0).all()                  # ... after the kept factor had migrated there
+        if not opts:
+            assert ((stats["path"] & 48) == 48).all()            # started in the wavefront kernel, handed over
+
+
+def test_k0_start_n512_freeK(pkg, orc):
+    """warm start with NO free variable at N = 512 (S = DN everywhere, z = d): the first pass is freeK!
+    (SSQP.jl:35-59) on the full N x N product, which releases every variable whose gradient allows"""
+    cfg = pkg.CONFIGS["cfg4"]
+    prob = pkg.generate_batch(cfg, 3, 4711)
+    P, N, J = 3, cfg.N, cfg.J
+    S0 = np.full((P, N + J), pkg.DN, dtype=np.int32)
+    S0[:, N:] = pkg.OE
+    x0 = prob["d"].copy()
+    zo, So, sto, _, _ = _oracle_fast(orc, prob, S0, x0)
+    ctx = pkg.default_context()
+    for opts in (dict(), dict(wave_kernel=0)):
+        with ctx.options(**opts):
+            db = pkg.DeviceBatch(prob, S0, x0, ntrace=8)
+            db.solve()
+            r = db.results()
+        assert np.array_equal(r["status"], sto), (r["status"], sto)
+        conv = sto > 0
+        assert np.array_equal(r["S"][conv], So[conv])
+        assert (r["trace"][:, 0, 2] == 0).all() and (r["trace"][:, 0, 0] == 0).all()   # pass 1: a K == 0 pass
+        if conv.any():
+            scale = np.maximum(np.abs(zo[conv]).max(axis=1), 1e-300)
+            assert (np.abs(r["z"][conv] - zo[conv]).max(axis=1) / scale).max() < 1e-10
+
+
+def test_cfg4_j0_family(pkg, orc):
+    """the J = 0 variant of the headline family"""
+    rel, stats = run_cfg(pkg, orc, pkg.CONFIGS["cfg4_j0"], 24)
+    assert ((stats["path"] & 16) != 0).all()
+
+
+def test_cfg3_full_batch_1024(pkg, orc):
+    """BASELINE.json configs[2] at full size: 1024 x N=256, K up to ~230 (wavefront kernel -> hand-over)"""
+    rel, stats = run_cfg(pkg, orc, pkg.CONFIGS["cfg3"], 1024, both=False)
+    assert stats["max_k"].max() > 200
+
+
+@pytest.mark.parametrize("N", [768, 601])
+def test_wide_n_kernels(pkg, orc, N):
+    """N in 513..1024 even (ssqp_solve_kernel<3,1>: eight accumulator slots per lane) and odd N > 512 (scalar loads
+    with the maximum number of per-thread slots)"""
+    cfg = pkg.GenConfig(N, 1, 3, 2 * N, 1e-3, 4.0 / N, 1.05, 0.1)
+    run_cfg(pkg, orc, cfg, 2, seed0=1234 + N)
+
+
+def test_two_contexts_one_device_agree_with_one(pkg, orc):
+    """ssqp_solve_batch_multi_f64: contiguous blocks over two contexts (here both on device 0, each with its own
+    host thread, stream and workspace) give exactly the single-context results"""
+    cfg = pkg.GenConfig(96, 1, 5, 192, 1e-3, 0.07, 1.03, 0.1)
+    prob = pkg.generate_batch(cfg, 257, 2024)      # (odd count: the last block is shorter)
+    x0, S0, st = pkg.phase1_batch(prob)
+    assert (st == 1).all()
+    z1, S1, st1, d1 = pkg.solveQP_batch(prob, S0, x0)
+    dev = pkg.default_context().device
+    ctxs = [pkg.Context(dev), pkg.Context(dev)]
+    z2, S2, st2, d2 = pkg.solveQP_batch_multi(prob, S0, x0, ctxs)
+    assert np.array_equal(S1, S2) and np.array_equal(st1, st2) and np.array_equal(z1, z2)
+    z3, S3, st3, d3 = pkg.solveQP_batch_multi(prob, S0, x0, ctxs + [pkg.Context(dev)])
+    assert np.array_equal(S1, S3) and np.array_equal(st1, st3) and np.array_equal(z1, z3)
+    zo, So, sto, _, _ = oracle_batch(orc, prob, S0, x0)
+    assert_parity(z2, S2, st2, zo, So, sto)
+
+
+def test_long_runs_refresh_caches(pkg, orc):
+    """many status switches at nonzero bounds (lower bounds > 0): hq and bEall follow by one column per switch and are
+    re-evaluated from (z, S) every 64 switches -- the decisions stay those of the oracle over several hundred passes"""
+    rng = np.random.default_rng(99 + SEED_SHIFT)
+    cfg = pkg.GenConfig(256, 1, 6, 512, 1e-3, 5.0 / 256, 1.0, 0.2)
+    prob = pkg.generate_batch(cfg, 16, 555)
+    prob["d"][:] = rng.uniform(0.0, 0.3 / 256, size=prob["d"].shape)
+    x0, S0, st = pkg.phase1_batch(prob)
+    ok = st == 1
+    assert ok.sum() >= 8
+    sub = {k: np.ascontiguousarray(v[ok]) for k, v in prob.items()}
+    zo, So, sto, _, _ = oracle_batch(orc, sub, S0[ok], x0[ok])
+    assert (sto > 150).any()
+    ctx = pkg.default_context()
+    for opts in (dict(), dict(wave_kernel=0)):
+        with ctx.options(**opts):
+            z, S, status, detail = pkg.solveQP_batch(sub, S0[ok], x0[ok])
+        assert_parity(z, S, status, zo, So, sto)

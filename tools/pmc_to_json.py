@@ -1,0 +1,43 @@
+"""Builds gpurun_out/prof_<tag>/pmc_counters.json from the PMC passes of tools/profile_round.sh: per-launch means
+of every counter, summed over the two solve kernels of a launch (wavefront kernel + workgroup kernel), stamped with
+the sha256 of the kernel sources so that bench.py only quotes them for the code they were taken on.
+usage: python tools/pmc_to_json.py <tag>   (copy the result to profiles/pmc_counters.json)"""
+import collections, csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+tag = sys.argv[1]
+base = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+
+
+def per_launch(passdir):
+    """{counter: mean over launches of the sum over the solve kernels of one launch}"""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))   # counter -> kernel -> values per dispatch
+    for f in glob.glob(os.path.join(base, passdir, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            kn = r["Kernel_Name"]
+            if "ssqp_solve_kernel" in kn or "ssqp_wave_kernel" in kn:
+                acc[r["Counter_Name"]]["wave" if "wave" in kn else "wg"].append(float(r["Counter_Value"]))
+    out = {}
+    for c, d in acc.items():
+        out[c] = sum(sum(v) / len(v) for v in d.values())
+    return out
+
+
+res = {"config": "cfg4", "nprob": 1024, "tag": tag, "kernel_source_sha256": bench.kernel_source_hash(),
+       "correction": "FETCH_SIZE x2 on gfx950 for 16-B-per-lane streaming reads (MI355X_MICROARCH.md, HBM section); "
+                     "WRITE_SIZE exact; separate --pmc passes (tools/profile_round.sh); rocprofv3 reports KiB; "
+                     "figures are per launch = wavefront kernel + workgroup kernel of one batch"}
+for mode, key in (("default", "default_formulation"), ("dense", "dense_formulation")):
+    f = per_launch("pmc_fetch_" + mode).get("FETCH_SIZE")
+    w = per_launch("pmc_write_" + mode).get("WRITE_SIZE")
+    if f is None or w is None:
+        continue
+    res[key] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
+sq = {}
+for p in ("pmc_sq1_default", "pmc_sq2_default", "pmc_sq3_default"):
+    sq.update(per_launch(p))
+if sq and "default_formulation" in res:
+    res["default_formulation"]["sq"] = sq
+json.dump(res, open(os.path.join(base, "pmc_counters.json"), "w"), indent=1)
+print(json.dumps(res, indent=1))

@@ -1,0 +1,24 @@
+#!/bin/bash
+# GPU box: the round's rocprofv3 evidence for bench.py's workload (cfg4, 1024 QPs, serial launches):
+#   kernel-trace --stats for the default and the dense formulation, then SEPARATE --pmc passes (counters only):
+#   FETCH_SIZE, WRITE_SIZE (HBM bytes), two SQ groups (issue / wait / instruction mix).
+# usage: tools/profile_round.sh <tag>        -> gpurun_out/prof_<tag>/ (+ pmc_counters.json, ready for profiles/)
+set -o pipefail
+TAG=$1
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --skip-dense --streams 1"
+run() { name=$1; shift; timeout -k 10 400 "$@" > $OUT/$name.log 2>&1 || { echo "FAILED $name"; tail -5 $OUT/$name.log; exit 1; }; }
+run trace_default rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_default -- $B --steps 5 --warmup 1
+run trace_dense   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_dense   -- $B --steps 3 --warmup 1 --dense
+run trace_lanes   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_lanes   -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --skip-dense --streams 3 --steps 9 --warmup 1
+run fetch_default rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_default -- $B --steps 1 --warmup 0
+run write_default rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_default -- $B --steps 1 --warmup 0
+run fetch_dense   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_dense -- $B --steps 1 --warmup 0 --dense
+run write_dense   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_dense -- $B --steps 1 --warmup 0 --dense
+run sq1_default   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc_sq1_default -- $B --steps 1 --warmup 0
+run sq2_default   rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2_default -- $B --steps 1 --warmup 0
+run sq3_default   rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_INSTS_BRANCH SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq3_default -- $B --steps 1 --warmup 0
+python3 $GRAFT_REPO_ROOT/tools/pmc_to_json.py $TAG
+find $OUT -name "*kernel_stats.csv"
