@@ -110,6 +110,9 @@ const char *ssqp_last_error(const ssqp_ctx *ctx);
  *   "dense_gamma"     1: the reference's dense formulation (from-scratch factor, gamma pass over all N columns,
  *                     SSQP.jl:322,352) -- the HBM roofline measurement; default 0
  *   "wg_per_cu"       workgroups per CU of the workgroup kernel: 0 = automatic (default), 1, 2
+ *   "pin_host_buffers" 1: ssqp_solve_batch_f64 page-locks the caller's V array in place (hipHostRegister) and keeps it
+ *                     registered until it is called with another array or the context is destroyed: uploads at
+ *                     the full PCIe rate for hosts that solve out of the same buffers repeatedly; default 0
  * Unknown names / out-of-range values: SSQP_ERR_ARG. */
 int ssqp_ctx_set_option(ssqp_ctx *ctx, const char *name, int value);
 int ssqp_ctx_get_option(ssqp_ctx *ctx, const char *name, int *value);
@@ -136,12 +139,28 @@ int ssqp_solve_full_f64(ssqp_ctx *ctx, int N, int M, int J, const double *V, con
                         int64_t *status, int32_t *detail);
 
 /* ---- batches of independent QPs of equal shape --------------------------- */
-/* Host buffers, problems stored back to back (problem p at offset p*len). */
+/* Host buffers, problems stored back to back (problem p at offset p*len).  Large batches go up in chunks of about
+ * 256 MiB of V and every chunk is solved on one of four internal launch lanes as soon as it has landed: the call takes
+ * the PCIe transfer plus one chunk's solve. */
 int ssqp_solve_batch_f64(ssqp_ctx *ctx, int nprob, int N, int M, int J, const double *V,
                          const double *A, const double *G, const double *q, const double *b,
                          const double *g, const double *d, const double *u, int32_t *S,
                          const double *x0, double *z, const ssqp_settings *settings,
                          int64_t *status, int32_t *detail, ssqp_stats *stats);
+
+/* A batch KEPT in HBM: upload the problem data once, solve it any number of times -- warm starts from another
+ * (S, x0) (the three-argument solveQP, SSQP.jl:237), efficient-frontier sweeps that only replace q or b
+ * (QP(P, q, L) / QP(P, mu, q), types.jl:303-339).  ssqp_problem_solve moves only S, x0 in and z, S, status out
+ * (about 6 KB per N = 512 problem instead of 2 MiB of V).  `which` of ssqp_problem_set_vector: 0 q, 1 b, 2 g,
+ * 3 d, 4 u (arrays of nprob * length, problems back to back). */
+typedef struct ssqp_problem ssqp_problem;
+int ssqp_problem_upload(ssqp_ctx *ctx, int nprob, int N, int M, int J, const double *V, const double *A,
+                        const double *G, const double *q, const double *b, const double *g, const double *d,
+                        const double *u, ssqp_problem **out);
+int ssqp_problem_set_vector(ssqp_problem *p, int which, const double *data);
+int ssqp_problem_solve(ssqp_problem *p, int32_t *S, const double *x0, double *z, const ssqp_settings *settings,
+                       int64_t *status, int32_t *detail, ssqp_stats *stats);
+int ssqp_problem_free(ssqp_problem *p);
 
 /* The same over SEVERAL contexts -- normally one per GPU of the node (ssqp_ctx_create(dev, ...) for dev = 0..G-1):
  * the batch is cut into contiguous blocks, context r solves problems [r*ceil(P/G), (r+1)*ceil(P/G)) on its own

@@ -8,10 +8,10 @@ The directory name contains a dot, so it is loaded through
 """
 from . import _capi, dist
 from ._capi import LIB_PATH, NoDeviceError, SSQPError
-from .solver import (BASE_SEED, CONFIGS, Context, DeviceBatch, GenConfig, default_context, generate_batch,
+from .solver import (BASE_SEED, CONFIGS, Context, DeviceBatch, GenConfig, ResidentBatch, default_context, generate_batch,
                      phase1_batch, solveQP, solveQP_batch, solveQP_batch_multi)
 from .types import DN, EO, IN, OE, UP, QP, DimensionMismatch, Settings, Status
 
 __all__ = ["Status", "IN", "DN", "UP", "OE", "EO", "Settings", "QP", "solveQP", "solveQP_batch", "solveQP_batch_multi", "Context",
-           "DeviceBatch", "GenConfig", "CONFIGS", "BASE_SEED", "generate_batch", "phase1_batch", "NoDeviceError",
+           "DeviceBatch", "ResidentBatch", "GenConfig", "CONFIGS", "BASE_SEED", "generate_batch", "phase1_batch", "NoDeviceError",
            "SSQPError", "DimensionMismatch", "LIB_PATH", "default_context"]

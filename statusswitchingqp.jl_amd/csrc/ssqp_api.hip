@@ -33,10 +33,24 @@ struct ssqp_ctx {
     int optIncremental = 1;  // 0: refactor V[F,F] from scratch in every pass
     int optWaveKernel = 1;   // 0: never use the wavefront-per-QP kernel
     int optWaveQPC = 4;      // QPs (wavefronts) per CU of the wavefront kernel: 4..8
+    int optPinHost = 0;      // 1: page-lock the caller's V array (kept registered until another array comes)
+    const void *pinnedPtr = nullptr;
+    size_t pinnedBytes = 0;
     // grow-only device workspaces
     DevBuf Ct, rhs, queue, gscratch, fbList, fbIter, wscratch, p1ws, p1wsInt;
     // staging buffers of the host-pointer entry points
     DevBuf hV, hA, hG, hq, hb, hg, hd, hu, hS, hx0, hz, hstatus, hdetail, hstats;
+    // launch lanes of the host-buffer batch entry: child contexts (own stream, workspaces, work counters) so that
+    // the solve of one chunk overlaps the upload of the next and the solves of neighbouring chunks
+    std::vector<ssqp_ctx *> lanes;
+    hipEvent_t evCopy[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+// a batch resident in HBM (ssqp_problem_upload): solved any number of times without moving V again
+struct ssqp_problem {
+    ssqp_ctx *ctx = nullptr;
+    int nprob = 0, N = 0, M = 0, J = 0;
+    DevBuf V, A, G, q, b, g, d, u, S, x0, z, status, detail, stats;
 };
 
 namespace {
@@ -112,6 +126,12 @@ int ssqp_ctx_destroy(ssqp_ctx *c) {
     if (!c) return SSQP_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->pinnedPtr) (void)hipHostUnregister(const_cast<void *>(c->pinnedPtr));
+    c->pinnedPtr = nullptr;
+    for (ssqp_ctx *l : c->lanes) (void)ssqp_ctx_destroy(l);
+    c->lanes.clear();
+    for (hipEvent_t &e : c->evCopy)
+        if (e) (void)hipEventDestroy(e), e = nullptr;
     for (DevBuf *b : {&c->Ct, &c->rhs, &c->queue, &c->gscratch, &c->fbList, &c->fbIter, &c->wscratch, &c->p1ws, &c->p1wsInt, &c->hV, &c->hA, &c->hG, &c->hq, &c->hb, &c->hg,
                       &c->hd, &c->hu, &c->hS, &c->hx0, &c->hz, &c->hstatus, &c->hdetail, &c->hstats})
         release(*b);
@@ -131,6 +151,7 @@ static int *option_slot(ssqp_ctx *c, const char *name) {
     if (!std::strcmp(name, "incremental")) return &c->optIncremental;
     if (!std::strcmp(name, "wave_kernel")) return &c->optWaveKernel;
     if (!std::strcmp(name, "wave_qp_per_cu")) return &c->optWaveQPC;
+    if (!std::strcmp(name, "pin_host_buffers")) return &c->optPinHost;
     return nullptr;
 }
 int ssqp_ctx_set_option(ssqp_ctx *c, const char *name, int value) {
@@ -141,7 +162,7 @@ int ssqp_ctx_set_option(ssqp_ctx *c, const char *name, int value) {
     }
     if ((slot == &c->optWgPerCU && (value < 0 || value > ssqp::MAX_WG_PER_CU)) ||
         (slot == &c->optWaveQPC && (value < 1 || value > 8)) ||
-        ((slot == &c->optDenseGamma || slot == &c->optIncremental || slot == &c->optWaveKernel) &&
+        ((slot == &c->optDenseGamma || slot == &c->optIncremental || slot == &c->optWaveKernel || slot == &c->optPinHost) &&
          (value != 0 && value != 1))) {
         c->err = std::string("option value out of range: ") + name;
         return SSQP_ERR_ARG;
@@ -309,6 +330,22 @@ int ssqp_generate_V_dev(ssqp_ctx *c, const ssqp_gen_cfg *cfg, uint64_t seed0, in
                ? SSQP_OK : SSQP_ERR_HIP;
 }
 
+// child context number i of c (created on first use, options follow the parent at every call)
+static ssqp_ctx *lane_of(ssqp_ctx *c, int i) {
+    while ((int)c->lanes.size() <= i) {
+        ssqp_ctx *l = nullptr;
+        if (ssqp_ctx_create(c->device, &l) != SSQP_OK) return nullptr;
+        c->lanes.push_back(l);
+    }
+    ssqp_ctx *l = c->lanes[(size_t)i];
+    l->optWgPerCU = c->optWgPerCU;
+    l->optDenseGamma = c->optDenseGamma;
+    l->optIncremental = c->optIncremental;
+    l->optWaveKernel = c->optWaveKernel;
+    l->optWaveQPC = c->optWaveQPC;
+    return l;
+}
+
 int ssqp_solve_batch_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const double *V, const double *A,
                          const double *G, const double *q, const double *b, const double *g, const double *d,
                          const double *u, int32_t *S, const double *x0, double *z, const ssqp_settings *settings,
@@ -322,27 +359,74 @@ int ssqp_solve_batch_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const doub
     if (nprob == 0) return SSQP_OK;
     if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return SSQP_ERR_HIP;
     const size_t P = nprob, n = N, m = M, j = J;
-    struct Up { DevBuf *buf; const void *src; size_t bytes; };
-    const Up ups[] = {{&c->hV, V, P * n * n * 8}, {&c->hA, A, P * m * n * 8}, {&c->hG, G, P * j * n * 8},
-                      {&c->hq, q, P * n * 8},     {&c->hb, b, P * m * 8},     {&c->hg, g, P * j * 8},
-                      {&c->hd, d, P * n * 8},     {&c->hu, u, P * n * 8},     {&c->hS, S, P * (n + j) * 4},
-                      {&c->hx0, x0, P * n * 8}};
-    for (const Up &up : ups) {
-        if (!ensure(c, *up.buf, up.bytes)) return SSQP_ERR_ALLOC;
-        if (up.bytes && up.src &&
-            !hip_ok(c, hipMemcpyAsync(up.buf->p, up.src, up.bytes, hipMemcpyHostToDevice, c->stream), "H2D"))
-            return SSQP_ERR_HIP;
-    }
+    struct Up { DevBuf *buf; const void *src; size_t per; };  // bytes per problem
+    const Up ups[] = {{&c->hV, V, n * n * 8}, {&c->hA, A, m * n * 8}, {&c->hG, G, j * n * 8}, {&c->hq, q, n * 8},
+                      {&c->hb, b, m * 8},     {&c->hg, g, j * 8},     {&c->hd, d, n * 8},     {&c->hu, u, n * 8},
+                      {&c->hS, S, (n + j) * 4}, {&c->hx0, x0, n * 8}};
+    for (const Up &up : ups)
+        if (!ensure(c, *up.buf, up.per * P)) return SSQP_ERR_ALLOC;
     if (!ensure(c, c->hz, P * n * 8) || !ensure(c, c->hstatus, P * 8) || !ensure(c, c->hdetail, P * 4) ||
         !ensure(c, c->hstats, P * sizeof(ssqp_stats)))
         return SSQP_ERR_ALLOC;
-    rc = ssqp_solve_batch_dev_f64(c, nprob, N, M, J, (const double *)c->hV.p, (const double *)c->hA.p,
-                                  (const double *)c->hG.p, (const double *)c->hq.p, (const double *)c->hb.p,
-                                  (const double *)c->hg.p, (const double *)c->hd.p, (const double *)c->hu.p,
-                                  (int32_t *)c->hS.p, (const double *)c->hx0.p, (double *)c->hz.p, settings,
-                                  (int64_t *)c->hstatus.p, (int32_t *)c->hdetail.p, (ssqp_stats *)c->hstats.p,
-                                  nullptr, 0, c->stream);
-    if (rc != SSQP_OK) return rc;
+    // The upload of V (N*N*8 bytes per QP over PCIe) dwarfs the solve: the batch goes up in chunks, and every chunk is
+    // solved on one of four launch lanes (child contexts) as soon as it has landed -- the solves run behind the
+    // upload of the following chunks and beside each other, so the call takes the transfer plus one chunk's solve.
+    const size_t vbytes = P * n * n * 8;
+    if (c->optPinHost && (c->pinnedPtr != (const void *)V || c->pinnedBytes != vbytes)) {
+        // page-lock V where it lies: the upload then runs at the full PCIe rate and truly asynchronously.  The
+        // registration (tens of ms for 2 GiB) is kept for the next call with the same array -- a host that solves
+        // out of the same buffers again and again pays it once.
+        if (c->pinnedPtr) (void)hipHostUnregister(const_cast<void *>(c->pinnedPtr));
+        c->pinnedPtr = nullptr;
+        if (hipHostRegister(const_cast<double *>(V), vbytes, hipHostRegisterDefault) == hipSuccess) {
+            c->pinnedPtr = V;
+            c->pinnedBytes = vbytes;
+        } else {
+            (void)hipGetLastError();  // (not fatal: the pageable path still works)
+        }
+    }
+    int nchunk = 1;
+    if (vbytes > ((size_t)64 << 20)) nchunk = (int)((vbytes + ((size_t)256 << 20) - 1) / ((size_t)256 << 20));
+    if (nchunk > nprob) nchunk = nprob;
+    const int per = (nprob + nchunk - 1) / nchunk;
+    const int nlane = nchunk > 1 ? 4 : 1;
+    for (int i = 0; i < 4; ++i)
+        if (!c->evCopy[i] && !hip_ok(c, hipEventCreateWithFlags(&c->evCopy[i], hipEventDisableTiming), "hipEventCreate"))
+            return SSQP_ERR_HIP;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const size_t lo = (size_t)ch * per;
+        const size_t cnt = (lo + per <= P) ? (size_t)per : P - lo;
+        if (cnt == 0) break;
+        ssqp_ctx *l = nlane > 1 ? lane_of(c, ch % nlane) : c;
+        if (!l) return SSQP_ERR_ALLOC;
+        for (const Up &up : ups)
+            if (up.per && up.src &&
+                !hip_ok(c, hipMemcpyAsync((char *)up.buf->p + lo * up.per, (const char *)up.src + lo * up.per, cnt * up.per,
+                                          hipMemcpyHostToDevice, c->stream), "H2D"))
+                return SSQP_ERR_HIP;
+        hipStream_t ls = l->stream;
+        if (l != c) {
+            if (!hip_ok(c, hipEventRecord(c->evCopy[ch % 4], c->stream), "hipEventRecord") ||
+                !hip_ok(c, hipStreamWaitEvent(ls, c->evCopy[ch % 4], 0), "hipStreamWaitEvent"))
+                return SSQP_ERR_HIP;
+        }
+        auto at = [&](DevBuf &bf, size_t perb) { return (void *)((char *)bf.p + lo * perb); };
+        rc = ssqp_solve_batch_dev_f64(l, (int)cnt, N, M, J, (const double *)at(c->hV, n * n * 8),
+                                      (const double *)at(c->hA, m * n * 8), (const double *)at(c->hG, j * n * 8),
+                                      (const double *)at(c->hq, n * 8), (const double *)at(c->hb, m * 8),
+                                      (const double *)at(c->hg, j * 8), (const double *)at(c->hd, n * 8),
+                                      (const double *)at(c->hu, n * 8), (int32_t *)at(c->hS, (n + j) * 4),
+                                      (const double *)at(c->hx0, n * 8), (double *)at(c->hz, n * 8), settings,
+                                      (int64_t *)at(c->hstatus, 8), (int32_t *)at(c->hdetail, 4),
+                                      (ssqp_stats *)at(c->hstats, sizeof(ssqp_stats)), nullptr, 0, ls);
+        if (rc != SSQP_OK) {
+            if (l != c) c->err = l->err;
+            return rc;
+        }
+    }
+    for (int i = 0; i < nlane && nlane > 1; ++i)
+        if (i < (int)c->lanes.size() && !hip_ok(c, hipStreamSynchronize(c->lanes[(size_t)i]->stream), "hipStreamSynchronize"))
+            return SSQP_ERR_HIP;
     if (!hip_ok(c, hipMemcpyAsync(z, c->hz.p, P * n * 8, hipMemcpyDeviceToHost, c->stream), "D2H") ||
         !hip_ok(c, hipMemcpyAsync(S, c->hS.p, P * (n + j) * 4, hipMemcpyDeviceToHost, c->stream), "D2H") ||
         !hip_ok(c, hipMemcpyAsync(status, c->hstatus.p, P * 8, hipMemcpyDeviceToHost, c->stream), "D2H"))
@@ -354,6 +438,94 @@ int ssqp_solve_batch_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const doub
         return SSQP_ERR_HIP;
     if (!hip_ok(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return SSQP_ERR_HIP;
     return SSQP_OK;
+}
+
+// ---- a batch kept in HBM: upload once, solve many times (warm starts, sweeps over q / b) ----
+int ssqp_problem_upload(ssqp_ctx *c, int nprob, int N, int M, int J, const double *V, const double *A, const double *G,
+                        const double *q, const double *b, const double *g, const double *d, const double *u,
+                        ssqp_problem **out) {
+    if (!out) return SSQP_ERR_ARG;
+    *out = nullptr;
+    int rc = check_dims(c, nprob, N, M, J);
+    if (rc != SSQP_OK) return rc;
+    if (nprob <= 0 || !V || !q || !d || !u || (M > 0 && (!A || !b)) || (J > 0 && (!G || !g))) {
+        c->err = "null pointer";
+        return SSQP_ERR_ARG;
+    }
+    if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return SSQP_ERR_HIP;
+    ssqp_problem *p = new (std::nothrow) ssqp_problem();
+    if (!p) return SSQP_ERR_ALLOC;
+    p->ctx = c; p->nprob = nprob; p->N = N; p->M = M; p->J = J;
+    const size_t P = nprob, n = N, m = M, j = J;
+    struct Up { DevBuf *buf; const void *src; size_t bytes; };
+    const Up ups[] = {{&p->V, V, P * n * n * 8}, {&p->A, A, P * m * n * 8}, {&p->G, G, P * j * n * 8}, {&p->q, q, P * n * 8},
+                      {&p->b, b, P * m * 8},     {&p->g, g, P * j * 8},     {&p->d, d, P * n * 8},     {&p->u, u, P * n * 8}};
+    bool ok = true;
+    for (const Up &up : ups) {
+        ok = ok && ensure(c, *up.buf, up.bytes);
+        if (ok && up.bytes && up.src)
+            ok = hip_ok(c, hipMemcpyAsync(up.buf->p, up.src, up.bytes, hipMemcpyHostToDevice, c->stream), "H2D");
+    }
+    ok = ok && ensure(c, p->S, P * (n + j) * 4) && ensure(c, p->x0, P * n * 8) && ensure(c, p->z, P * n * 8) &&
+         ensure(c, p->status, P * 8) && ensure(c, p->detail, P * 4) && ensure(c, p->stats, P * sizeof(ssqp_stats));
+    ok = ok && hip_ok(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    if (!ok) {
+        (void)ssqp_problem_free(p);
+        return SSQP_ERR_ALLOC;
+    }
+    *out = p;
+    return SSQP_OK;
+}
+
+int ssqp_problem_free(ssqp_problem *p) {
+    if (!p) return SSQP_OK;
+    if (p->ctx) (void)hipSetDevice(p->ctx->device);
+    for (DevBuf *b : {&p->V, &p->A, &p->G, &p->q, &p->b, &p->g, &p->d, &p->u, &p->S, &p->x0, &p->z, &p->status, &p->detail,
+                      &p->stats})
+        release(*b);
+    delete p;
+    return SSQP_OK;
+}
+
+int ssqp_problem_set_vector(ssqp_problem *p, int which, const double *data) {
+    if (!p || !data || which < 0 || which > 4) return SSQP_ERR_ARG;
+    ssqp_ctx *c = p->ctx;
+    DevBuf *bufs[] = {&p->q, &p->b, &p->g, &p->d, &p->u};
+    const size_t len[] = {(size_t)p->N, (size_t)p->M, (size_t)p->J, (size_t)p->N, (size_t)p->N};
+    const size_t bytes = (size_t)p->nprob * len[which] * 8;
+    if (bytes == 0) return SSQP_OK;
+    if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return SSQP_ERR_HIP;
+    if (!hip_ok(c, hipMemcpyAsync(bufs[which]->p, data, bytes, hipMemcpyHostToDevice, c->stream), "H2D") ||
+        !hip_ok(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize"))
+        return SSQP_ERR_HIP;
+    return SSQP_OK;
+}
+
+int ssqp_problem_solve(ssqp_problem *p, int32_t *S, const double *x0, double *z, const ssqp_settings *settings,
+                       int64_t *status, int32_t *detail, ssqp_stats *stats) {
+    if (!p || !S || !x0 || !z || !status) return SSQP_ERR_ARG;
+    ssqp_ctx *c = p->ctx;
+    const size_t P = p->nprob, n = p->N, j = p->J;
+    if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return SSQP_ERR_HIP;
+    if (!hip_ok(c, hipMemcpyAsync(p->S.p, S, P * (n + j) * 4, hipMemcpyHostToDevice, c->stream), "H2D") ||
+        !hip_ok(c, hipMemcpyAsync(p->x0.p, x0, P * n * 8, hipMemcpyHostToDevice, c->stream), "H2D"))
+        return SSQP_ERR_HIP;
+    int rc = ssqp_solve_batch_dev_f64(c, p->nprob, p->N, p->M, p->J, (const double *)p->V.p, (const double *)p->A.p,
+                                      (const double *)p->G.p, (const double *)p->q.p, (const double *)p->b.p,
+                                      (const double *)p->g.p, (const double *)p->d.p, (const double *)p->u.p,
+                                      (int32_t *)p->S.p, (const double *)p->x0.p, (double *)p->z.p, settings,
+                                      (int64_t *)p->status.p, (int32_t *)p->detail.p, (ssqp_stats *)p->stats.p, nullptr, 0,
+                                      c->stream);
+    if (rc != SSQP_OK) return rc;
+    if (!hip_ok(c, hipMemcpyAsync(z, p->z.p, P * n * 8, hipMemcpyDeviceToHost, c->stream), "D2H") ||
+        !hip_ok(c, hipMemcpyAsync(S, p->S.p, P * (n + j) * 4, hipMemcpyDeviceToHost, c->stream), "D2H") ||
+        !hip_ok(c, hipMemcpyAsync(status, p->status.p, P * 8, hipMemcpyDeviceToHost, c->stream), "D2H"))
+        return SSQP_ERR_HIP;
+    if (detail && !hip_ok(c, hipMemcpyAsync(detail, p->detail.p, P * 4, hipMemcpyDeviceToHost, c->stream), "D2H"))
+        return SSQP_ERR_HIP;
+    if (stats && !hip_ok(c, hipMemcpyAsync(stats, p->stats.p, P * sizeof(ssqp_stats), hipMemcpyDeviceToHost, c->stream), "D2H"))
+        return SSQP_ERR_HIP;
+    return hip_ok(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize") ? SSQP_OK : SSQP_ERR_HIP;
 }
 
 int ssqp_phase1_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const double *dA, const double *dG,

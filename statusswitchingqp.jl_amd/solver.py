@@ -219,6 +219,47 @@ def solveQP_batch(prob, S, x0, settings=None, ctx=None, want_stats=False):
     return z, S, status, detail
 
 
+class ResidentBatch:
+    """A batch kept in HBM behind the C ABI (ssqp_problem_upload): solve it repeatedly from host (S, x0) without
+    moving V again -- the warm-start entry solveQP(Q, S, x0) (SSQP.jl:237) for a whole batch."""
+    _VEC = dict(q=0, b=1, g=2, d=3, u=4)
+
+    def __init__(self, prob, ctx=None):
+        self.ctx = ctx or default_context()
+        self.P, self.N = prob["q"].shape
+        self.M, self.J = prob["b"].shape[1], prob["g"].shape[1]
+        arrs = [_f64(prob[k]) for k in "VAGqbgdu"]
+        self._h = C.c_void_p()
+        _capi.check(_capi.lib().ssqp_problem_upload(self.ctx.handle, self.P, self.N, self.M, self.J,
+                                                    *[_p(a) for a in arrs], C.byref(self._h)), self.ctx.handle)
+
+    def set_vector(self, name, data):
+        data = _f64(data)
+        _capi.check(_capi.lib().ssqp_problem_set_vector(self._h, self._VEC[name], _p(data)), self.ctx.handle)
+
+    def solve(self, S, x0, settings=None):
+        S = np.ascontiguousarray(S, dtype=np.int32).copy()
+        x0 = _f64(x0)
+        z = np.zeros((self.P, self.N))
+        status = np.zeros(self.P, dtype=np.int64)
+        detail = np.zeros(self.P, dtype=np.int32)
+        cs = _csettings(settings)
+        _capi.check(_capi.lib().ssqp_problem_solve(self._h, _p(S), _p(x0), _p(z), C.byref(cs), _p(status), _p(detail),
+                                                   None), self.ctx.handle)
+        return z, S, status, detail
+
+    def close(self):
+        if self._h:
+            _capi.lib().ssqp_problem_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def solveQP_batch_multi(prob, S, x0, ctxs, settings=None):
     """The batch cut into contiguous blocks over several contexts (one per GPU; ssqp_solve_batch_multi_f64)."""
     P, N = prob["q"].shape

@@ -447,3 +447,86 @@ def test_long_runs_refresh_caches(pkg, orc):
         with ctx.options(**opts):
             z, S, status, detail = pkg.solveQP_batch(sub, S0[ok], x0[ok])
         assert_parity(z, S, status, zo, So, sto)
+
+
+# ---------------------------------------------------------------- Phase-1 on the GPU (ssqp_phase1_batch_dev_f64)
+def _phase1_gpu(pkg, prob):
+    P, N = prob["q"].shape
+    db = pkg.DeviceBatch(prob, np.zeros((P, N + prob["g"].shape[1]), dtype=np.int32), np.zeros((P, N)))
+    st = db.phase1()
+    db.torch.cuda.synchronize()
+    return db.x0.cpu().numpy(), db.S0.cpu().numpy(), st.cpu().numpy()
+
+
+@pytest.mark.parametrize("name,nprob", [("cfg1", 32), ("cfg2", 8), ("cfg4", 256), ("cfg3", 64)])
+def test_phase1_gpu_bit_identical_to_host(pkg, orc, name, nprob):
+    """initQP + cDantzigLP (SSQP.jl:461-560, Simplex.jl:445-615) on the GPU: the vertex (x0, S0) and the status are
+    bit for bit those of the host C++ stage and of the oracle -- so the loop that follows runs the same passes"""
+    cfg = pkg.CONFIGS[name]
+    prob = pkg.generate_batch(cfg, nprob)
+    xh, Sh, sth = pkg.phase1_batch(prob)
+    xo, So, sto = orc.initQP_batch(prob["A"], prob["G"], prob["b"], prob["g"], prob["d"], prob["u"])
+    xg, Sg, stg = _phase1_gpu(pkg, prob)
+    assert np.array_equal(stg, sth) and np.array_equal(stg, sto)
+    assert np.array_equal(Sg, Sh) and np.array_equal(Sg, So)
+    assert np.array_equal(xg, xh) and np.array_equal(xg, xo)
+
+
+@pytest.mark.parametrize("kind", ["plain", "lower_bounds", "negative_lower", "dup_rows", "some_free", "infeasible"])
+def test_phase1_gpu_variations(pkg, orc, kind):
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(("p1" + kind).encode()) + SEED_SHIFT)
+    for (N, M, J) in [(24, 1, 0), (40, 1, 3), (57, 2, 4), (96, 3, 8), (200, 1, 2), (128, 2, 20)]:
+        ub = rng.uniform(2.0, 6.0) / N if kind != "some_free" else 0.0
+        cfg = pkg.GenConfig(N, M, J, 2 * N, 1e-3, ub, rng.uniform(0.93, 1.1), rng.uniform(0.0, 0.3))
+        prob = pkg.generate_batch(cfg, 10, int(rng.integers(1, 2 ** 31)))
+        if kind == "infeasible":
+            prob["u"][:] = 0.5 / N               # the budget cannot be met: sum(u) = 1/2 < 1
+        else:
+            prob = _mutate(prob, rng, kind)
+        xh, Sh, sth = pkg.phase1_batch(prob)
+        xg, Sg, stg = _phase1_gpu(pkg, prob)
+        assert np.array_equal(stg, sth), (kind, N, M, J, stg, sth)
+        assert np.array_equal(Sg, Sh) and np.array_equal(xg, xh), (kind, N, M, J)
+        if kind == "infeasible":
+            assert (sth == 0).all()
+
+
+def test_end_to_end_on_device(pkg, orc):
+    """solveQP(Q) with both stages on the GPU: Phase-1 kernel, then the loop, nothing returns to the host in between"""
+    cfg = pkg.CONFIGS["cfg4"]
+    prob = pkg.generate_batch(cfg, 96)
+    P, N, J = 96, cfg.N, cfg.J
+    db = pkg.DeviceBatch(prob, np.zeros((P, N + J), dtype=np.int32), np.zeros((P, N)))
+    st = db.phase1()
+    db.solve()
+    r = db.results()
+    assert (st.cpu().numpy() == 1).all()
+    x0, S0, _ = pkg.phase1_batch(prob)
+    zo, So, sto, _, _ = oracle_batch(orc, prob, S0, x0)
+    assert_parity(r["z"], r["S"], r["status"], zo, So, sto)
+
+
+def test_host_buffer_chunked_and_resident_handle(pkg, orc):
+    """ssqp_solve_batch_f64 uploads a large batch in chunks and solves them on internal launch lanes; the resident
+    handle (ssqp_problem_upload / _solve / _set_vector) solves without moving V again: same results either way"""
+    cfg = pkg.GenConfig(256, 1, 4, 512, 1e-3, 5.0 / 256, 1.05, 0.1)
+    prob = pkg.generate_batch(cfg, 300, 8675309)            # 300 x 512 KiB = 150 MiB of V: more than one chunk
+    x0, S0, st = pkg.phase1_batch(prob)
+    assert (st == 1).all()
+    z, S, status, detail = pkg.solveQP_batch(prob, S0, x0)
+    zo, So, sto, _, _ = oracle_batch(orc, prob, S0, x0)
+    assert_parity(z, S, status, zo, So, sto)
+    rb = pkg.ResidentBatch(prob)
+    z2, S2, st2, _ = rb.solve(S0, x0)
+    assert np.array_equal(z2, z) and np.array_equal(S2, S) and np.array_equal(st2, status)
+    z3, S3, st3, _ = rb.solve(S, z)                          # warm start at the optimum: a fixed point
+    assert np.array_equal(S3, S) and (st3 >= 1).all() and (st3 <= 3).all()
+    q2 = 2.0 * prob["q"]                                     # an efficient-frontier step: only q is replaced
+    rb.set_vector("q", q2)
+    z4, S4, st4, _ = rb.solve(S0, x0)
+    prob2 = dict(prob)
+    prob2["q"] = q2
+    zo2, So2, sto2, _, _ = oracle_batch(orc, prob2, S0, x0)
+    assert_parity(z4, S4, st4, zo2, So2, sto2)
+    rb.close()
