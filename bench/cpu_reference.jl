@@ -3,7 +3,7 @@
 # someone with Julia runs this.  The inputs are bit-identical to bench.py's: they come from the library's own
 # generator through ccall (ssqp_generate_batch, include/ssqp_hip.h; it needs no GPU).
 #
-#   julia -t auto bench_ref/cpu_reference.jl /path/to/libssqp_hip.so [cfg4] [nprob=64]
+#   julia -t auto bench/cpu_reference.jl /path/to/libssqp_hip.so [cfg4] [nprob=64]
 #
 # One QP per Julia thread, BLAS.set_num_threads(1) (the reference has no parallelism of its own); reports
 # QPs/s of solveQP(Q, S, x0) (SSQP.jl:237 -- the hot path, Phase-1 outside the timed region) and of solveQP(Q).
