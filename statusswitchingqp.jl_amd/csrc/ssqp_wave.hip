@@ -231,6 +231,8 @@ struct WLds {
     double *tv;     // right-hand side of the lambda solve
     double *aLrow;  // alphaL by row id
     double *yn;     // 16 doubles: a new border row / the downdate vector
+    double *GG;     // MJX x MJX, symmetric, full: Gram matrix of the rows of [A;G][:, F]: GG[a][b] = sum_r X[a]_r X[b]_r
+    double *xn;     // 16 doubles: a column of [A;G] (for the rank-1 change of GG)
     int16_t *ra;    // kept row ids in order
 };
 
@@ -587,6 +589,62 @@ __device__ __forceinline__ void h_rank1(const WLds &L, double scale) {  // H += 
     }
 }
 
+// GG += sign * xn xn'  (two entries per lane)
+__device__ __forceinline__ void gg_rank1(const WLds &L, double sign) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = lane + 64 * q;
+        if (e < MJX * MJX) {
+            const int a = e / MJX, b = e - a * MJX;
+            L.GG[e] = fma(L.xn[a] * sign, L.xn[b], L.GG[e]);
+        }
+    }
+}
+
+// Can getRowsGJr purge a row of X = [AE bE] at all?  After the eliminations by the rows kept before it, row i of the
+// filter is the one vector of x_i + span(previous rows) that vanishes in the pivot columns -- whatever columns the
+// reference picks, its 2-norm is at least delta_i = dist(x_i, span(previous rows)), so its largest entry is at least
+// delta_i / sqrt(K + 1).  The delta_i^2 are the pivots of the LDL' factorisation of the Gram matrix X X' of the
+// active rows: when every pivot exceeds its threshold (orders of magnitude above both tol^2 (K+1) and the rounding of
+// the kept Gram matrix) no row can be purged and the filter's result is "all rows kept" -- exactly, without running
+// it.  Lane i holds row i of the W0 x W0 Gram matrix of the active rows (row-id order, ids in L.ra).
+template <int WM>
+__device__ __forceinline__ bool full_rank_certified(const WLds &L, double bEv, int W0) {
+    const int lane = lane_id();
+    const int ri = L.ra[lane < W0 ? lane : 0];
+    const double bei = bperm_f64(bEv, ri);
+    double a[WM];
+#pragma unroll
+    for (int c = 0; c < WM; ++c) {
+        const int rc = L.ra[c < W0 ? c : 0];
+        const double bec = readlane_f64(bEv, rc);
+        const double v = fma(bei, bec, L.GG[ri * MJX + rc]);
+        a[c] = (lane < W0 && c < W0) ? v : 0.0;
+    }
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < WM; ++c) {
+        if (c < W0) {  // uniform
+            const double d = readlane_f64(a[c], c);
+            const int rc = L.ra[c];
+            const double bec = readlane_f64(bEv, rc);
+            const double thr = fmax(1e-8, 1e-6 * fma(bec, bec, L.GG[rc * MJX + rc]));
+            if (!(d > thr)) ok = false;
+            const double r = fast_rcp(d > thr ? d : 1.0);
+            const double lic = a[c] * r;
+#pragma unroll
+            for (int c2 = 0; c2 < WM; ++c2) {
+                if (c2 > c) {
+                    const double bq = readlane_f64(a[c], c2);
+                    a[c2] = fma(-lic, bq, a[c2]);
+                }
+            }
+        }
+    }
+    return ok;
+}
+
 }  // namespace wv
 
 using namespace wv;
@@ -723,8 +781,10 @@ __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int 
             L.yn[w] = 0.0;
         }
     }
+    if (lane < 16) L.xn[lane] = (lane < MJ) ? cj : 0.0;
     wave_sync();
     h_rank1(L, rdn);
+    gg_rank1(L, 1.0);
     wave_sync();
     C.sRead += 64ll * K + 64ll * MJ + 16;
     K += 1;
@@ -764,6 +824,20 @@ __device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p
         }
         wave_sync();
         h_rank1(L, -1.0 / mpp);
+        wave_sync();
+    }
+    {   // the Gram matrix of the rows of [A;G][:, F] loses the column of the deleted variable
+        double xp = 0.0;
+#pragma unroll
+        for (int w = 0; w < MJX; ++w) {
+            if (w < MJ) {
+                const double xw = rbcast<SL>(R.X[w], p);
+                xp = (lane == w) ? xw : xp;
+            }
+        }
+        if (lane < 16) L.xn[lane] = xp;
+        wave_sync();
+        gg_rank1(L, -1.0);
         wave_sync();
     }
     delete_compact<SL>(L.F, K, p);
@@ -885,19 +959,32 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
     const int W0 = __popc(act);
     // ---- rank filter on [AE bE]  (SSQP.jl:310-319)
     unsigned kept = act;
-    if (W0 > 0) {
-        if (SL == 1) kept = rank_filter<1>(R, S.bEv, act, K, tol);
-        else kept = rank_filter<2>(R, S.bEv, act, K, tol);
-    }
-    const int W = __popc(kept);
-    WPH(0);  // rank filter
-    // kept row ids in order; alphaL by row id
     if (lane < MJX + 1) L.aLrow[lane] = 0.0;
-    {
-        const unsigned below = kept & ((1u << (lane & 31)) - 1u);
-        if (lane < MJX && ((kept >> lane) & 1u)) L.ra[__popc(below)] = (int16_t)lane;
+    {   // active row ids in order (the kept ones, unless the filter below purges some)
+        const unsigned below = act & ((1u << (lane & 31)) - 1u);
+        if (lane < MJX && ((act >> lane) & 1u)) L.ra[__popc(below)] = (int16_t)lane;
     }
     wave_sync();
+    if (W0 > 0) {
+        // usually the Gram matrix of the active rows proves that the filter cannot purge anything
+        bool certified = false;
+        if (K + 1 >= W0) {
+            if (W0 > 8) certified = full_rank_certified<MJX>(L, S.bEv, W0);
+            else if (W0 > 4) certified = full_rank_certified<8>(L, S.bEv, W0);
+            else certified = full_rank_certified<4>(L, S.bEv, W0);
+        }
+        if (!certified) {
+            if (SL == 1) kept = rank_filter<1>(R, S.bEv, act, K, tol);
+            else kept = rank_filter<2>(R, S.bEv, act, K, tol);
+            if (kept != act) {
+                const unsigned below = kept & ((1u << (lane & 31)) - 1u);
+                if (lane < MJX && ((kept >> lane) & 1u)) L.ra[__popc(below)] = (int16_t)lane;
+                wave_sync();
+            }
+        }
+    }
+    const int W = __popc(kept);
+    WPH(0);  // rank filter (or the certificate that replaces it)
     // ---- Schur system (AE V^-1 AE') lam = bE + AE V^-1 c ; alphaL = -lam  (SSQP.jl:325-328, 351)
     if (W > 0) {
         for (int e = lane; e < W * W; e += 64) {
@@ -1330,6 +1417,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
             S.cDirty = false;
         } else {
             for (int e = lane; e < NR * NR; e += 64) L.H[e] = 0.0;
+            for (int e = lane; e < MJX * MJX; e += 64) L.GG[e] = 0.0;
             wave_sync();
         }
     }
@@ -1448,6 +1536,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     S.appJ = -1;
     S.appAll = true;
     for (int e = lane; e < NR * NR; e += 64) L.H[e] = 0.0;
+    for (int e = lane; e < MJX * MJX; e += 64) L.GG[e] = 0.0;
     wave_sync();
     C.sRead += 8ll * N + 4ll * (N + J);
 
@@ -1613,6 +1702,8 @@ __global__ __launch_bounds__(64, 1) void ssqp_wave_kernel(SolveParams P) {
         L.tv = d0 + o; o += 16;
         L.aLrow = d0 + o; o += 16;
         L.yn = d0 + o; o += 16;
+        L.GG = d0 + o; o += MJX * MJX + 1;
+        L.xn = d0 + o; o += 16;
         L.ra = reinterpret_cast<int16_t *>(d0 + o);
     }
     double *gscr = P.wscratch + (size_t)blockIdx.x * P.wscratchStride;
@@ -1630,7 +1721,7 @@ bool wave_kernel_applies(int N, int M, int J) {
 }
 int wave_lds_bytes(int rc) {
     const int r1 = rc > 64 ? rc - 64 : 0;
-    const int dbl = 2080 + rc * r1 + 2 + NR * NR + 2 * (MJX * MJX + 1) + 16 * 3 + 8;
+    const int dbl = 2080 + rc * r1 + 2 + NR * NR + 3 * (MJX * MJX + 1) + 16 * 4 + 8;
     return dbl * 8;
 }
 size_t wave_scratch_doubles(int N, int M, int J) {
