@@ -287,7 +287,7 @@ __device__ __forceinline__ void fac_put(const Fac &F, int r, int c, double v, bo
 // lnew = the new row of L (for the border update).  Returns the new pivot (must be > 0).
 template <int SL>
 __device__ __forceinline__ double append_row(const Fac &F, Rows &R, int K, int j, const double *__restrict__ V, int N,
-                                             double (&lnew)[2]) {
+                                             double (&lnew)[2], double (&vraw)[2], double (&ysub)[2]) {
     const int lane = lane_id();
     const double *__restrict__ col = V + (size_t)j * N;
     const double vjj = col[j];
@@ -298,6 +298,8 @@ __device__ __forceinline__ double append_row(const Fac &F, Rows &R, int K, int j
         const double v = col[r < K ? R.ord[t] : j];
         y[t] = (r < K) ? v : 0.0;
     }
+    vraw[0] = y[0];
+    vraw[1] = y[1];
     {
         double lc[4][2], ln[4][2];
         load_cols4<SL>(F, K, 0, lc);
@@ -317,6 +319,8 @@ __device__ __forceinline__ double append_row(const Fac &F, Rows &R, int K, int j
                 for (int t = 0; t < SL; ++t) lc[u][t] = ln[u][t];
         }
     }
+    ysub[0] = y[0];
+    ysub[1] = y[1];
     double part = 0.0;
     lnew[0] = lnew[1] = 0.0;
 #pragma unroll
@@ -452,6 +456,12 @@ template <int SL>
 __device__ __forceinline__ void load_rowT(const Fac &F, int r, double (&l)[2]) {
     const int lane = lane_id();
     l[0] = l[1] = 0.0;
+    if (SL == 1) {  // (no branch: rows <= 0 have no live lane)
+        const bool live = lane < r;
+        const double x = F.L0[live ? cofs64(lane) - lane + r : 0];
+        l[0] = live ? x : 0.0;
+        return;
+    }
     if (r <= 0) return;  // uniform
     if (r < 64) {
         const bool live = lane < r;
@@ -645,6 +655,60 @@ __device__ __forceinline__ bool full_rank_certified(const WLds &L, double bEv, i
     return ok;
 }
 
+// lambda of the Schur system H[kept,kept] lam = bE[kept] + t[kept] (W <= WM), one wavefront: lane i takes row i of
+// the kept block straight from the kept 12 x 12 matrix (row ids in L.ra) -- no staging copy; eliminations broadcast
+// the pivot row with v_readlane; the unit-lower factor goes to `tr` column by column so that the back substitution
+// needs one broadcast per step.  Returns false when a pivot is not > 0 (cholesky(C) of the reference throws).
+template <int WM>
+__device__ __forceinline__ bool schur_solve(const WLds &L, double bEv, int W, double &lam) {
+    const int lane = lane_id();
+    const int ri = L.ra[lane < W ? lane : 0];
+    double a[WM];
+#pragma unroll
+    for (int c = 0; c < WM; ++c) {
+        const int rc = L.ra[c < W ? c : 0];
+        const double v = L.H[ri * NR + rc];
+        a[c] = (lane < W && c < W) ? v : 0.0;
+    }
+    double y = bperm_f64(bEv, ri) + L.H[ri * NR + CC];
+    y = (lane < W) ? y : 0.0;
+    double *tr = L.tr;
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < WM; ++c) {
+        if (c < W) {  // uniform
+            const double d = readlane_f64(a[c], c);
+            if (!(d > 0.0)) ok = false;
+            const double r = fast_rcp(d);
+            const double yc = readlane_f64(y, c);
+            const double lic = a[c] * r;
+            const bool below = lane > c;
+            y = below ? fma(-lic, yc, y) : ((lane == c) ? y * r : y);
+#pragma unroll
+            for (int c2 = 0; c2 < WM; ++c2) {
+                if (c2 > c) {
+                    const double bq = readlane_f64(a[c], c2);
+                    a[c2] = fma(-lic, bq, a[c2]);
+                }
+            }
+            if (below && lane < WM) tr[c * WM + lane] = lic;
+        }
+    }
+    wave_sync();
+    double u[WM];
+#pragma unroll
+    for (int i = 1; i < WM; ++i) u[i] = tr[(lane < WM ? lane : 0) * WM + i];
+#pragma unroll
+    for (int i = WM - 1; i >= 1; --i) {
+        if (i < W) {  // uniform
+            const double xi = readlane_f64(y, i);
+            y = (lane < i) ? fma(-u[i], xi, y) : y;
+        }
+    }
+    lam = y;
+    return ok;
+}
+
 }  // namespace wv
 
 using namespace wv;
@@ -734,17 +798,29 @@ __device__ __forceinline__ void recompute_H_all(const WLds &L, const Rows &R, in
 
 // Append variable j: factor row, per-row registers, border row, Schur block.  Returns false when the new pivot is
 // not > 0 (cholesky(V[F,F]) of the reference throws, SSQP.jl:322).
+// dz != 0: the variable leaves B at a nonzero value, so c = hq[F] has just changed by dz * V[F, j] for the rows already
+// in the factor (hq itself is up to date).  L^-1 V[F, j] is the vector this append substitutes anyway, so the border
+// column y_c and t = H[:, c] follow in O(K) instead of a re-gather, a re-sweep and eleven sums:
+//   y_c += dz * y,   H[w][c] += dz * sum_r Y[w]_r lnew_r  (the same sums the new border row needs).
 template <int SL>
 __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int &K, int j, const double2 (&hq)[NCH],
-                                           const double2 (&zd)[NCH]) {
+                                           const double2 (&zd)[NCH], double dz) {
     const int lane = lane_id();
     const int N = C.N, MJ = C.MJ;
     // everything the new row needs from memory is requested before the factor sweep: one round trip, hidden
     const double cj = C.Ct[(size_t)(lane < MJ ? lane : 0) * N + j];  // column j of [A;G], row w in lane w
     const double uj = C.uhi[j], dj = C.dlo[j];
-    double lnew[2];
-    const double dnew = append_row<SL>(L.F, R, K, j, C.V, N, lnew);
+    double lnew[2], vraw[2], ysub[2];
+    const double dnew = append_row<SL>(L.F, R, K, j, C.V, N, lnew, vraw, ysub);
     if (!(dnew > 0.0)) return false;
+    if (dz != 0.0) {  // uniform
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + KSLOT * t;
+            R.Y[CC][t] = (r < K) ? fma(dz, ysub[t], R.Y[CC][t]) : R.Y[CC][t];
+            R.cF[t] = (r < K) ? fma(dz, vraw[t], R.cF[t]) : R.cF[t];
+        }
+    }
     const double rdn = fast_rcp(dnew);
     // rank among the free variables by index: rows with a larger index move up by one
     int below = 0;
@@ -774,6 +850,11 @@ __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int 
             for (int t = 0; t < SL; ++t) s = (lane + KSLOT * t < K) ? fma(lnew[t], R.Y[w][t], s) : s;
             s = wave_sum(s);
             const double yk = xw - s;
+            if (dz != 0.0 && w < MJX && lane == 0) {  // t_w = H[w][c] follows the change of c
+                const double hv = fma(dz, s, L.H[w * NR + CC]);
+                L.H[w * NR + CC] = hv;
+                L.H[CC * NR + w] = hv;
+            }
             if (w < MJX) set_row<SL>(R.X[w < MJX ? w : 0], K, xw);
             set_row<SL>(R.Y[w], K, yk);
             if (lane == 0) L.yn[w] = yk;
@@ -940,6 +1021,7 @@ struct WState {
     // pending changes of F decided by the last pass
     unsigned long long del0, del1;  // rows to delete (slot 0 / slot 1 lanes)
     int appJ;                       // variable to append, or -1
+    double relDz;                   // the shift of z[appJ] that hq has already followed (0: none)
     bool appAll;                    // append every variable with status IN that has no row (start, after freeK!)
 };
 
@@ -987,21 +1069,12 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
     WPH(0);  // rank filter (or the certificate that replaces it)
     // ---- Schur system (AE V^-1 AE') lam = bE + AE V^-1 c ; alphaL = -lam  (SSQP.jl:325-328, 351)
     if (W > 0) {
-        for (int e = lane; e < W * W; e += 64) {
-            const int a = e % W, b = e / W;
-            L.Hs[a + W * b] = L.H[(int)L.ra[a] * NR + (int)L.ra[b]];
-        }
-        {   // right-hand side bE + t, t = AE V^-1 c = H[:, c]
-            const int a = L.ra[lane < W ? lane : 0];
-            const double be = bperm_f64(S.bEv, a);
-            if (lane < W) L.tv[lane] = be + L.H[a * NR + CC];
-        }
-        wave_sync();
         double lam = 0.0;
         bool okH = true;
-        if (W > 8) okH = small_spd_solve<MJX>(L.Hs, L.tv, W, lam, L.tr);
-        else if (W > 4) okH = small_spd_solve<8>(L.Hs, L.tv, W, lam, L.tr);
-        else okH = small_spd_solve<4>(L.Hs, L.tv, W, lam, L.tr);
+        if (W > 8) okH = schur_solve<MJX>(L, S.bEv, W, lam);
+        else if (W > 6) okH = schur_solve<8>(L, S.bEv, W, lam);
+        else if (W > 4) okH = schur_solve<6>(L, S.bEv, W, lam);
+        else okH = schur_solve<4>(L, S.bEv, W, lam);
         if (!okH) {  // cholesky(C) of the reference throws (SSQP.jl:328)
             C.ret = -1;
             C.det = SSQP_DETAIL_POSDEF_C;
@@ -1315,10 +1388,12 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
             const int jv = ev.ord;
             st_set(S.Sp, jv, SSQP_IN);
             const double zr = dense_get(S.zd, jv);
+            S.relDz = 0.0;
             if (zr != 0.0) {  // B loses a column with a nonzero weight
                 bound_shift(C, S.hq, S.bEv, jv, -zr);
                 S.nShift += 1;
                 S.cDirty = true;
+                S.relDz = -zr;
                 C.sRead += 8ll * N + 64ll * MJ;
             }
             S.appJ = jv;
@@ -1423,16 +1498,22 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
     }
     if (ndel > 0) WPH(11);  // border sweep + H column after deletes
     if (S.appJ >= 0 || S.appAll) {
+        double dzFold = 0.0;
         if (S.cDirty && S.K > 0) {  // c changed for the rows already in the factor
-            regather_c<SL>(R, S.K, S.hq);
-            border_sweep<SL>(L.F, R, S.K, 1u << CC);
-            recompute_H_c<SL>(L, R, S.K, MJ);
+            if (S.appJ >= 0 && S.relDz != 0.0) {
+                dzFold = S.relDz;  // ... by the released variable's column only: folded into its append
+            } else {
+                regather_c<SL>(R, S.K, S.hq);
+                border_sweep<SL>(L.F, R, S.K, 1u << CC);
+                recompute_H_c<SL>(L, R, S.K, MJ);
+            }
         }
         WPH(12);  // c refresh before an append
         S.cDirty = false;
+        S.relDz = 0.0;
         if (S.appJ >= 0) {
             if (S.K + 1 > C.RC) return W_HANDOVER;
-            if (!append_var<SL>(C, L, R, S.K, S.appJ, S.hq, S.zd)) {
+            if (!append_var<SL>(C, L, R, S.K, S.appJ, S.hq, S.zd, dzFold)) {
                 C.ret = -1;
                 C.det = SSQP_DETAIL_POSDEF_V;
                 return W_BREAK;
@@ -1455,7 +1536,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
                             const int jv = 2 * l + 128 * m + e;
                             // (variables that already have a row are not in this state: the factor is empty)
                             if (S.K + 1 > C.RC || S.K + 1 > 64 * SL - 1) return W_HANDOVER;
-                            if (!append_var<SL>(C, L, R, S.K, jv, S.hq, S.zd)) {
+                            if (!append_var<SL>(C, L, R, S.K, jv, S.hq, S.zd, 0.0)) {
                                 C.ret = -1;
                                 C.det = SSQP_DETAIL_POSDEF_V;
                                 return W_BREAK;
@@ -1534,6 +1615,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     S.nShift = 0;
     S.del0 = S.del1 = 0ull;
     S.appJ = -1;
+    S.relDz = 0.0;
     S.appAll = true;
     for (int e = lane; e < NR * NR; e += 64) L.H[e] = 0.0;
     for (int e = lane; e < MJX * MJX; e += 64) L.GG[e] = 0.0;
@@ -1553,6 +1635,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
         if (S.nShift >= 64) S.hbValid = false;
         if (!S.hbValid) {
             S.nShift = 0;
+            S.relDz = 0.0;  // (the re-evaluation changes c for every row: the full refresh runs)
             refresh_caches(C, S.hq, S.bEv, S.zd, S.Sp);
             S.hbValid = true;
             S.cDirty = true;
