@@ -344,11 +344,12 @@ __device__ __forceinline__ double append_row(const Fac &F, Rows &R, int K, int j
 // row/column is removed from the packed storage.  pv receives p_k = (L33^-1 l)_k in row k (the downdate of H
 // and nothing else needs it); dg/rd of the rows > p are updated in place (still in their OLD positions).
 template <int SL>
-__device__ __forceinline__ void delete_update(const Fac &F, Rows &R, int K, int p, double (&pv)[2]) {
+__device__ __forceinline__ void delete_update(const Fac &F, Rows &R, int K, int p, double (&pv)[2], double (&bt)[2]) {
     const int lane = lane_id();
     double w[2];
     load_col<SL>(F, K, p, w);
     pv[0] = pv[1] = 0.0;
+    bt[0] = bt[1] = 0.0;
     double alpha = rbcast<SL>(R.dg, p);
     double lc[2], ln[2];
     load_col<SL>(F, K, p + 1, lc);
@@ -367,6 +368,7 @@ __device__ __forceinline__ void delete_update(const Fac &F, Rows &R, int K, int 
                 R.dg[t] = dn;
                 R.rd[t] = rdn;
                 pv[t] = pk;
+                bt[t] = beta;
             }
             const bool below = r > k && r < K;
             w[t] = below ? fma(-pk, lc[t], w[t]) : w[t];
@@ -872,15 +874,84 @@ __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int 
     return true;
 }
 
+// Border rows after the deletion of row p without a re-sweep (one register slot, K <= 63).  The rank-1 update gives
+// L33' = L33 L~ with L~(r,k) = p_r beta_k below the diagonal, so the rows k > p of every border column follow from
+//   v_k = y_k + p_k y_p,   y'_k = v_k - p_k s_k,   s_{k+1} = a_k s_k + beta_k v_k  (s_{p+1} = 0),  a_k = d_k / d'_k:
+// a first-order recurrence = a scan of affine maps over the lanes (six ds_bpermute steps; the multipliers a are shared
+// by all columns).  The results stay in the OLD row positions; the caller shifts the rows up.
+__device__ __forceinline__ void border_update_scan(Rows &R, int K, int p, const double (&pv)[2], const double (&bt)[2],
+                                                   const double (&dgold)[2], int MJ) {
+    const int lane = lane_id();
+    const bool on = lane > p && lane < K;
+    double A = on ? dgold[0] * R.rd[0] : 1.0;
+    double Astep[6];
+#pragma unroll
+    for (int st = 0; st < 6; ++st) {
+        const int d = 1 << st;
+        Astep[st] = A;
+        const double Ap = bperm_f64(A, (lane - d) & 63);
+        A = (lane >= d) ? A * Ap : A;
+    }
+    const double pk = on ? pv[0] : 0.0, bk = on ? bt[0] : 0.0;
+#pragma unroll
+    for (int w = 0; w < NR; ++w) {
+        if (w < MJ || w == CC) {  // uniform
+            const double yp = rbcast<1>(R.Y[w], p);
+            const double v = on ? fma(pk, yp, R.Y[w][0]) : 0.0;
+            double B = bk * v;
+#pragma unroll
+            for (int st = 0; st < 6; ++st) {
+                const int d = 1 << st;
+                const double Bp = bperm_f64(B, (lane - d) & 63);
+                B = (lane >= d) ? fma(Astep[st], Bp, B) : B;
+            }
+            const double sk = bperm_f64(B, (lane - 1) & 63);  // exclusive: the state before row k
+            R.Y[w][0] = on ? fma(-pk, (lane >= 1) ? sk : 0.0, v) : R.Y[w][0];
+        }
+    }
+}
+
+// The variable of row p is about to leave F for a NONZERO bound: c = hq[F] has changed by dz * V[F, j] (hq itself is up
+// to date).  V[F, j] is column p of V_FF = L D L', so L^-1 V[F, j] = D L' e_p: the border column y_c and t = H[:, c]
+// follow from row p of the factor (before the row is deleted):  y_c,r += dz d_r L(p,r) (r <= p),  H[w][c] += dz X[w]_p.
+template <int SL>
+__device__ __forceinline__ void fold_block_shift(const WLds &L, Rows &R, int K, int p, int MJ, double dz) {
+    const int lane = lane_id();
+    double lrow[2];
+    load_rowT<SL>(L.F, p, lrow);
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int r = lane + KSLOT * t;
+        const double lr = (r == p) ? 1.0 : ((r < p) ? lrow[t] : 0.0);
+        R.Y[CC][t] = (r <= p) ? fma(dz * R.dg[t], lr, R.Y[CC][t]) : R.Y[CC][t];
+    }
+#pragma unroll
+    for (int w = 0; w < MJX; ++w) {
+        if (w < MJ) {  // uniform
+            const double xw = rbcast<SL>(R.X[w], p);
+            if (lane == 0) {
+                const double hv = fma(dz, xw, L.H[w * NR + CC]);
+                L.H[w * NR + CC] = hv;
+                L.H[CC * NR + w] = hv;
+            }
+        }
+    }
+    wave_sync();
+    (void)K;
+}
+
 // Delete row p (its variable left F).  single: the border rows and H are still those of the current factor, so
 // H follows by the block-inverse downdate; otherwise the caller re-forms H.
 template <int SL>
-__device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p, int MJ, bool downdate) {
+__device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p, int MJ, bool downdate, bool scan) {
     const int lane = lane_id();
-    double pv[2], rdold[2];
+    double pv[2], bt[2], rdold[2], dgold[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) rdold[t] = R.rd[t];
-    delete_update<SL>(L.F, R, K, p, pv);
+    for (int t = 0; t < 2; ++t) {
+        rdold[t] = R.rd[t];
+        dgold[t] = R.dg[t];
+    }
+    delete_update<SL>(L.F, R, K, p, pv, bt);
     if (downdate) {
         // H' = H - g g' / m,  g = [A;G c']' V_FF^-1 e_p = Y' D^-1 f,  m = (V_FF^-1)_pp = f' D^-1 f,
         // f = L^-1 e_p: f_p = 1, f_r = -p_r below (p = L33^-1 l, the vector the rank-1 update walks through)
@@ -907,6 +978,7 @@ __device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p
         h_rank1(L, -1.0 / mpp);
         wave_sync();
     }
+    if (SL == 1 && scan) border_update_scan(R, K, p, pv, bt, dgold, MJ);  // (after the downdate: that one needs the old rows)
     {   // the Gram matrix of the rows of [A;G][:, F] loses the column of the deleted variable
         double xp = 0.0;
 #pragma unroll
@@ -935,6 +1007,11 @@ __device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p
 #pragma unroll
     for (int w = 0; w < MJX; ++w)
         if (w < MJ) shift_up<SL>(R.X[w], p);
+    if (SL == 1 && scan) {
+#pragma unroll
+        for (int w = 0; w < NR; ++w)
+            if (w < MJ || w == CC) shift_up<SL>(R.Y[w], p);
+    }
     K -= 1;
 #pragma unroll
     for (int t = 0; t < SL; ++t) {
@@ -1022,6 +1099,8 @@ struct WState {
     unsigned long long del0, del1;  // rows to delete (slot 0 / slot 1 lanes)
     int appJ;                       // variable to append, or -1
     double relDz;                   // the shift of z[appJ] that hq has already followed (0: none)
+    double blkDz;                   // the same for the single variable a blocked step sent to a nonzero bound
+    bool cFstale;                   // R.cF lags behind hq[F] (only full re-sweeps of the border read it)
     bool appAll;                    // append every variable with status IN that has no row (start, after freeK!)
 };
 
@@ -1203,6 +1282,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
                     if (zn != 0.0) {
                         bound_shift(C, S.hq, S.bEv, jv, zn);
                         S.nShift += 1;
+                        S.blkDz = zn;  // (used only when this is the pass's single deletion)
                         S.cDirty = true;
                         C.sRead += 8ll * N + 64ll * MJ;
                     }
@@ -1211,6 +1291,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
             WPH(5);  // blocked: switches + bound shifts
             S.del0 = dm[0];
             S.del1 = dm[1];
+            if (__popcll(dm[0]) + __popcll(dm[1]) != 1) S.blkDz = 0.0;
             if (trace) {
                 int f = firstId;
                 f = min(f, dpp_i32<DPP_XOR1>(f));
@@ -1464,13 +1545,33 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
     const int ndel = __popcll(S.del0) + __popcll(S.del1);
     if (ndel > 0) {
         const bool single = (ndel == 1);
+        // A single deletion with one register slot: the border rows follow by a scan and H by the downdate, and when
+        // the variable went to a nonzero bound the change of c is folded in beforehand -- no re-gather, no re-sweep.
+        const bool fast = single && SL == 1 && (!S.cDirty || S.blkDz != 0.0);
+        if (fast) {
+            const int pl = 63 - __clzll(S.del0);
+            if (S.cDirty) {
+                fold_block_shift<SL>(L, R, S.K, pl, MJ, S.blkDz);
+                S.cFstale = true;
+            }
+            delete_var<SL>(L, R, S.K, pl, MJ, true, true);
+            S.del0 = S.del1 = 0ull;
+            S.cDirty = false;
+            S.blkDz = 0.0;
+            WPH(10);  // deletes (update + downdate + compaction + shifts)
+            if (S.K == 0) {
+                for (int e = lane; e < NR * NR; e += 64) L.H[e] = 0.0;
+                for (int e = lane; e < MJX * MJX; e += 64) L.GG[e] = 0.0;
+                wave_sync();
+            }
+        } else {
         // highest row first: deleting row p leaves the rows below p in place
         if (SL == 2) {
             unsigned long long dm = S.del1;
             while (dm) {
                 const int pl = 63 - __clzll(dm);
                 dm &= ~(1ull << pl);
-                delete_var<SL>(L, R, S.K, pl + KSLOT, MJ, single);
+                delete_var<SL>(L, R, S.K, pl + KSLOT, MJ, single, false);
             }
         }
         {
@@ -1478,13 +1579,15 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
             while (dm) {
                 const int pl = 63 - __clzll(dm);
                 dm &= ~(1ull << pl);
-                delete_var<SL>(L, R, S.K, pl, MJ, single);
+                delete_var<SL>(L, R, S.K, pl, MJ, single, false);
             }
         }
         WPH(10);  // deletes (update + downdate + compaction + shifts)
         S.del0 = S.del1 = 0ull;
+        S.blkDz = 0.0;
         if (S.K > 0) {
-            if (S.cDirty) regather_c<SL>(R, S.K, S.hq);
+            if (S.cDirty || S.cFstale) regather_c<SL>(R, S.K, S.hq);
+            S.cFstale = false;
             const unsigned cols = ((1u << MJ) - 1u) | (1u << CC);
             border_sweep<SL>(L.F, R, S.K, cols);
             if (!single) recompute_H_all<SL>(L, R, S.K, MJ);
@@ -1495,6 +1598,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
             for (int e = lane; e < MJX * MJX; e += 64) L.GG[e] = 0.0;
             wave_sync();
         }
+        }
     }
     if (ndel > 0) WPH(11);  // border sweep + H column after deletes
     if (S.appJ >= 0 || S.appAll) {
@@ -1504,6 +1608,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
                 dzFold = S.relDz;  // ... by the released variable's column only: folded into its append
             } else {
                 regather_c<SL>(R, S.K, S.hq);
+                S.cFstale = false;
                 border_sweep<SL>(L.F, R, S.K, 1u << CC);
                 recompute_H_c<SL>(L, R, S.K, MJ);
             }
@@ -1616,6 +1721,8 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     S.del0 = S.del1 = 0ull;
     S.appJ = -1;
     S.relDz = 0.0;
+    S.blkDz = 0.0;
+    S.cFstale = false;
     S.appAll = true;
     for (int e = lane; e < NR * NR; e += 64) L.H[e] = 0.0;
     for (int e = lane; e < MJX * MJX; e += 64) L.GG[e] = 0.0;
@@ -1636,6 +1743,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
         if (!S.hbValid) {
             S.nShift = 0;
             S.relDz = 0.0;  // (the re-evaluation changes c for every row: the full refresh runs)
+            S.blkDz = 0.0;
             refresh_caches(C, S.hq, S.bEv, S.zd, S.Sp);
             S.hbValid = true;
             S.cDirty = true;
