@@ -118,6 +118,10 @@ def run(args):
     ctx = pkg.Context(local)
     if args.dense:
         ctx.set_option("dense_gamma", 1)
+    # several launch lanes on one GPU: the (normally empty) hand-over launch is issued lazily, see include/ssqp_hip.h.
+    # With more than one rank the gather consumes the results stream-ordered, so everything stays queued.
+    lazy = 1 if (world == 1 and args.streams > 1) else 0
+    ctx.set_option("lazy_handover", lazy)
     # V (the N*N*T part) is generated on the GPU, bit-identical to the host generator; the small arrays and the
     # Phase-1 vertex (x0, S0) come from the host C++ (not timed: the metric is the hot path solveQP(Q,S,x0))
     batch, prob, x0, S0 = pkg.DeviceBatch.generated(cfg, args.nprob, pkg.BASE_SEED + rank * args.nprob, ctx=ctx,
@@ -134,6 +138,7 @@ def run(args):
     lanes = [(batch, stream)]
     for _ in range(1, nlanes):
         c2 = pkg.Context(local)
+        c2.set_option("lazy_handover", lazy)
         if args.dense:
             c2.set_option("dense_gamma", 1)
         lanes.append((batch.twin(c2), torch.cuda.Stream(dev)))
@@ -151,6 +156,8 @@ def run(args):
                 pkg.dist.gather_results(b.z, b.S, b.status)
 
     def fence():
+        for lb, lst in lanes:               # (lazy hand-over: every lane's last launch is settled)
+            lb.ctx.sync(lst.cuda_stream)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)

@@ -110,6 +110,12 @@ const char *ssqp_last_error(const ssqp_ctx *ctx);
  *   "dense_gamma"     1: the reference's dense formulation (from-scratch factor, gamma pass over all N columns,
  *                     SSQP.jl:322,352) -- the HBM roofline measurement; default 0
  *   "wg_per_cu"       workgroups per CU of the workgroup kernel: 0 = automatic (default), 1, 2
+ *   "lazy_handover"   1: the launch of the workgroup kernel on the wavefront kernel's hand-over list is not queued
+ *                     behind it but issued by ssqp_sync (or the next call on the context) and only when the list is
+ *                     not empty -- for hosts that keep several contexts busy on different streams (the queued launch
+ *                     would wait for a free CU even when it has nothing to do).  The results of a device-buffer call
+ *                     are then complete only after ssqp_sync(ctx, stream): do NOT consume them stream-ordered.
+ *                     Default 0 (everything is queued on the caller's stream)
  *   "pin_host_buffers" 1: ssqp_solve_batch_f64 page-locks the caller's V array in place (hipHostRegister) and keeps it
  *                     registered until it is called with another array or the context is destroyed: uploads at
  *                     the full PCIe rate for hosts that solve out of the same buffers repeatedly; default 0
@@ -196,6 +202,11 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *ctx, int nprob, int N, int M, int
                                      const double *dx0, double *dz, const ssqp_settings *settings,
                                      int64_t *dstatus, int32_t *ddetail, ssqp_stats *dstats,
                                      ssqp_trace *dtrace, int ntrace, void *stream);
+/* "lazy_handover" only: issues the launch the last call on ctx may still owe (waits for that call's wavefront kernel,
+ * not for the stream).  A host that reuses the call's in/out buffers (S is in/out) must flush BEFORE it queues work
+ * that overwrites them. */
+int ssqp_flush(ssqp_ctx *ctx);
+/* waits for `stream`; with "lazy_handover" it first issues the launch the last call on ctx may still owe */
 int ssqp_sync(ssqp_ctx *ctx, void *stream);
 /* duration in ms of the solve kernel of the most recent ssqp_solve_batch_dev_f64
  * on this ctx, from HIP events recorded on the launch stream (call after sync) */

@@ -33,6 +33,7 @@ struct ssqp_ctx {
     int optIncremental = 1;  // 0: refactor V[F,F] from scratch in every pass
     int optWaveKernel = 1;   // 0: never use the wavefront-per-QP kernel
     int optWaveQPC = 4;      // QPs (wavefronts) per CU of the wavefront kernel: 4..8
+    int optLazyHandover = 0; // 1: the hand-over launch is deferred to ssqp_sync / the next call and skipped when empty
     int optPinHost = 0;      // 1: page-lock the caller's V array (kept registered until another array comes)
     const void *pinnedPtr = nullptr;
     size_t pinnedBytes = 0;
@@ -40,6 +41,14 @@ struct ssqp_ctx {
     DevBuf Ct, rhs, queue, gscratch, fbList, fbIter, wscratch, p1ws, p1wsInt;
     // staging buffers of the host-pointer entry points
     DevBuf hV, hA, hG, hq, hb, hg, hd, hu, hS, hx0, hz, hstatus, hdetail, hstats;
+    // lazy hand-over: the launch the wavefront kernel may still owe (its hand-over count lands in pinned memory)
+    unsigned int *hostCount = nullptr;   // pinned
+    hipEvent_t evCount = nullptr;
+    bool pending = false;
+    ssqp::SolveParams pendP;
+    int pendGrid = 0, pendWg = 0;
+    size_t pendLds = 0;
+    hipStream_t pendStream = nullptr;
     // launch lanes of the host-buffer batch entry: child contexts (own stream, workspaces, work counters) so that
     // the solve of one chunk overlaps the upload of the next and the solves of neighbouring chunks
     std::vector<ssqp_ctx *> lanes;
@@ -128,6 +137,10 @@ int ssqp_ctx_destroy(ssqp_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->pinnedPtr) (void)hipHostUnregister(const_cast<void *>(c->pinnedPtr));
     c->pinnedPtr = nullptr;
+    if (c->hostCount) (void)hipHostFree(c->hostCount);
+    c->hostCount = nullptr;
+    if (c->evCount) (void)hipEventDestroy(c->evCount);
+    c->evCount = nullptr;
     for (ssqp_ctx *l : c->lanes) (void)ssqp_ctx_destroy(l);
     c->lanes.clear();
     for (hipEvent_t &e : c->evCopy)
@@ -152,6 +165,7 @@ static int *option_slot(ssqp_ctx *c, const char *name) {
     if (!std::strcmp(name, "wave_kernel")) return &c->optWaveKernel;
     if (!std::strcmp(name, "wave_qp_per_cu")) return &c->optWaveQPC;
     if (!std::strcmp(name, "pin_host_buffers")) return &c->optPinHost;
+    if (!std::strcmp(name, "lazy_handover")) return &c->optLazyHandover;
     return nullptr;
 }
 int ssqp_ctx_set_option(ssqp_ctx *c, const char *name, int value) {
@@ -162,7 +176,8 @@ int ssqp_ctx_set_option(ssqp_ctx *c, const char *name, int value) {
     }
     if ((slot == &c->optWgPerCU && (value < 0 || value > ssqp::MAX_WG_PER_CU)) ||
         (slot == &c->optWaveQPC && (value < 1 || value > 8)) ||
-        ((slot == &c->optDenseGamma || slot == &c->optIncremental || slot == &c->optWaveKernel || slot == &c->optPinHost) &&
+        ((slot == &c->optDenseGamma || slot == &c->optIncremental || slot == &c->optWaveKernel || slot == &c->optPinHost ||
+          slot == &c->optLazyHandover) &&
          (value != 0 && value != 1))) {
         c->err = std::string("option value out of range: ") + name;
         return SSQP_ERR_ARG;
@@ -177,9 +192,31 @@ int ssqp_ctx_get_option(ssqp_ctx *c, const char *name, int *value) {
     return SSQP_OK;
 }
 
+// lazy hand-over: wait for the wavefront kernel of the last call, and launch the workgroup kernel on its hand-over
+// list only when that list is not empty (on the stream of that call, so later work on it stays ordered)
+static int finish_pending(ssqp_ctx *c) {
+    if (!c->pending) return SSQP_OK;
+    c->pending = false;
+    if (!hip_ok(c, hipEventSynchronize(c->evCount), "hipEventSynchronize")) return SSQP_ERR_HIP;
+    if (*c->hostCount == 0) return SSQP_OK;
+    if (!hip_ok(c, ssqp::launch_solve(c->pendP, c->pendGrid, c->pendLds, c->pendWg, c->pendStream), "solve launch"))
+        return SSQP_ERR_HIP;
+    if (!hip_ok(c, hipEventRecord(c->ev1, c->pendStream), "hipEventRecord")) return SSQP_ERR_HIP;
+    return SSQP_OK;
+}
+
+int ssqp_flush(ssqp_ctx *c) {
+    if (!c) return SSQP_ERR_ARG;
+    if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return SSQP_ERR_HIP;
+    return finish_pending(c);
+}
+
 int ssqp_sync(ssqp_ctx *c, void *stream) {
     if (!c) return SSQP_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;  // NULL is HIP's default stream, as everywhere in HIP
+    if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return SSQP_ERR_HIP;
+    const int rc = finish_pending(c);
+    if (rc != SSQP_OK) return rc;
     return hip_ok(c, hipStreamSynchronize(s), "hipStreamSynchronize") ? SSQP_OK : SSQP_ERR_HIP;
 }
 
@@ -188,6 +225,10 @@ int ssqp_last_kernel_ms(ssqp_ctx *c, float *ms) {
     if (!c->timed) {
         c->err = "no solve has been launched on this context";
         return SSQP_ERR_ARG;
+    }
+    {
+        const int rcp = finish_pending(c);
+        if (rcp != SSQP_OK) return rcp;
     }
     if (!hip_ok(c, hipEventSynchronize(c->ev1), "hipEventSynchronize")) return SSQP_ERR_HIP;
     return hip_ok(c, hipEventElapsedTime(ms, c->ev0, c->ev1), "hipEventElapsedTime") ? SSQP_OK : SSQP_ERR_HIP;
@@ -215,6 +256,10 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
     const ssqp_settings *st = settings ? settings : &def;
     if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return SSQP_ERR_HIP;
     hipStream_t s = (hipStream_t)stream;  // NULL is HIP's default stream (what torch uses unless told otherwise)
+    {
+        const int rcp = finish_pending(c);  // (lazy hand-over of the previous call on this context)
+        if (rcp != SSQP_OK) return rcp;
+    }
 
     const int MJ = M + J;
     // workgroups per CU: LDS is the limit.  3 when the N-vectors leave a useful arena in 1/3 of the 160 KiB,
@@ -306,6 +351,27 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
         if (!hip_ok(c, ssqp::launch_solve_wave(P, waveGrid, s), "wave solve launch")) return SSQP_ERR_HIP;
         P.queue = (unsigned int *)c->queue.p + 1;
         P.resume = 1;  // (a grid that finds the hand-over list empty exits at once)
+        if (c->optLazyHandover) {
+            // The workgroup kernel needs a CU with 80 KiB of LDS and four free register files: behind a launch of another
+            // context it would wait for that even when there is nothing to do.  Lazy mode: the hand-over count comes to
+            // pinned host memory and the launch is issued by ssqp_sync / the next call only if the count is not zero.
+            if (!c->hostCount && !hip_ok(c, hipHostMalloc((void **)&c->hostCount, 64, hipHostMallocDefault), "hipHostMalloc"))
+                return SSQP_ERR_ALLOC;
+            if (!c->evCount && !hip_ok(c, hipEventCreateWithFlags(&c->evCount, hipEventDisableTiming), "hipEventCreate"))
+                return SSQP_ERR_HIP;
+            if (!hip_ok(c, hipEventRecord(c->ev1, s), "hipEventRecord")) return SSQP_ERR_HIP;
+            if (!hip_ok(c, hipMemcpyAsync(c->hostCount, P.fbCount, 4, hipMemcpyDeviceToHost, s), "D2H") ||
+                !hip_ok(c, hipEventRecord(c->evCount, s), "hipEventRecord"))
+                return SSQP_ERR_HIP;
+            c->pendP = P;
+            c->pendGrid = grid;
+            c->pendWg = wgPerCU;
+            c->pendLds = (size_t)lay.total_bytes;
+            c->pendStream = s;
+            c->pending = true;
+            c->timed = true;
+            return SSQP_OK;
+        }
     }
     if (!hip_ok(c, ssqp::launch_solve(P, grid, (size_t)lay.total_bytes, wgPerCU, s), "solve launch")) return SSQP_ERR_HIP;
     if (!hip_ok(c, hipEventRecord(c->ev1, s), "hipEventRecord")) return SSQP_ERR_HIP;
@@ -343,6 +409,7 @@ static ssqp_ctx *lane_of(ssqp_ctx *c, int i) {
     l->optIncremental = c->optIncremental;
     l->optWaveKernel = c->optWaveKernel;
     l->optWaveQPC = c->optWaveQPC;
+    l->optLazyHandover = 1;  // (the batch entry finishes every lane before it copies the results back)
     return l;
 }
 
@@ -425,8 +492,14 @@ int ssqp_solve_batch_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const doub
         }
     }
     for (int i = 0; i < nlane && nlane > 1; ++i)
-        if (i < (int)c->lanes.size() && !hip_ok(c, hipStreamSynchronize(c->lanes[(size_t)i]->stream), "hipStreamSynchronize"))
-            return SSQP_ERR_HIP;
+        if (i < (int)c->lanes.size()) {
+            ssqp_ctx *l = c->lanes[(size_t)i];
+            const int rl = ssqp_sync(l, l->stream);
+            if (rl != SSQP_OK) {
+                c->err = l->err;
+                return rl;
+            }
+        }
     if (!hip_ok(c, hipMemcpyAsync(z, c->hz.p, P * n * 8, hipMemcpyDeviceToHost, c->stream), "D2H") ||
         !hip_ok(c, hipMemcpyAsync(S, c->hS.p, P * (n + j) * 4, hipMemcpyDeviceToHost, c->stream), "D2H") ||
         !hip_ok(c, hipMemcpyAsync(status, c->hstatus.p, P * 8, hipMemcpyDeviceToHost, c->stream), "D2H"))

@@ -82,6 +82,10 @@ class Context:
         _capi.check(_capi.lib().ssqp_last_kernel_ms(self._h, C.byref(ms)), self._h)
         return ms.value
 
+    def flush(self):
+        """lazy_handover: issue what the last call still owes before its in/out buffers are reused"""
+        _capi.check(_capi.lib().ssqp_flush(self._h), self._h)
+
     def sync(self, stream=None):
         _capi.check(_capi.lib().ssqp_sync(self._h, stream), self._h)
 
@@ -359,6 +363,7 @@ class DeviceBatch:
         Arrays given with a leading dimension of 1 are shared by every problem of the batch (stride 0)."""
         torch = self.torch
         cs = _csettings(settings)
+        self.ctx.flush()   # (lazy hand-over: the previous launch on this context is complete before S is reset)
         # S is in/out: the reset runs on the SAME stream as the launch (a raw hipStream_t is wrapped, so the copy
         # cannot race with the kernels of this or the previous launch on that stream)
         if stream is None:
@@ -401,6 +406,7 @@ class DeviceBatch:
         return self.p1status
 
     def results(self):
+        self.ctx.sync(C.c_void_p(self.torch.cuda.current_stream(self.S.device).cuda_stream))   # (settles a lazy hand-over)
         self.torch.cuda.synchronize(self.S.device)
         stats = np.frombuffer(self.stats.cpu().numpy().tobytes(), dtype=STATS_DTYPE).copy()
         trace = self.trace.cpu().numpy() if self.ntrace else None

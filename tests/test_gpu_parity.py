@@ -530,3 +530,35 @@ def test_host_buffer_chunked_and_resident_handle(pkg, orc):
     zo2, So2, sto2, _, _ = oracle_batch(orc, prob2, S0, x0)
     assert_parity(z4, S4, st4, zo2, So2, sto2)
     rb.close()
+
+
+def test_lazy_handover_agrees_with_eager(pkg, orc):
+    """"lazy_handover": the workgroup-kernel launch on the wavefront kernel's hand-over list is issued by ssqp_sync /
+    the next call and only when the list is not empty.  cfg3 hands every QP over (K -> 229 > the wavefront kernel's
+    factor), cfg1 none: both must give the eager results, also with two contexts interleaved on two streams."""
+    import torch
+    for name, nprob in (("cfg3", 48), ("cfg1", 64)):
+        cfg = pkg.CONFIGS[name]
+        b0, prob, x0, S0 = pkg.DeviceBatch.generated(cfg, nprob, 4242)
+        b0.solve()
+        ref = b0.results()
+        dev = b0.S.device
+        lanes = []
+        for _ in range(2):
+            c = pkg.Context(dev.index)
+            c.set_option("lazy_handover", 1)
+            lanes.append((b0.twin(c), torch.cuda.Stream(dev)))
+        for rep in range(3):
+            for b, st in lanes:
+                with torch.cuda.stream(st):
+                    b.solve()
+        for b, st in lanes:
+            with torch.cuda.stream(st):
+                r = b.results()
+            assert np.array_equal(r["S"], ref["S"]) and np.array_equal(r["status"], ref["status"])
+            assert np.array_equal(r["z"], ref["z"])
+            assert ((r["stats"]["path"] & 32) != 0).all() == (name == "cfg3")
+        full = dict(prob)
+        full["V"] = b0.t["V"].cpu().numpy()
+        zo, So, sto, _, _ = oracle_batch(orc, full, S0, x0)
+        assert_parity(ref["z"], ref["S"], ref["status"], zo, So, sto)
