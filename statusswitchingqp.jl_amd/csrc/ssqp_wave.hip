@@ -107,6 +107,42 @@ __device__ __forceinline__ double bperm_f64(double v, int src) {
     const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
+// NV wavefront sums at once (NV a multiple of 4): a butterfly that HALVES the number of vectors a lane carries in each
+// of its first two steps (lane pairs, then quads, exchange what the partner keeps), so the 64-lane reduction of NV
+// vectors costs about NV DPP-adds instead of 6 NV, and the dependent chain is one reduction deep instead of NV.
+// Afterwards vector w = i + (NV/4) b1 + (NV/2) b0 sits in slot i of every lane of class (b0, b1) = (lane & 1,
+// (lane >> 1) & 1); out[w] is handed to all lanes by v_readlane.
+template <int NV>
+__device__ __forceinline__ void wave_sum_multi(const double (&v)[NV], double (&out)[NV]) {
+    static_assert(NV % 4 == 0, "NV must be a multiple of 4");
+    constexpr int H = NV / 2, Q = NV / 4;
+    const int lane = lane_id();
+    const bool b0 = lane & 1, b1 = lane & 2;
+    double r[H], q[Q];
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        const double keep = b0 ? v[i + H] : v[i], send = b0 ? v[i] : v[i + H];
+        r[i] = keep + dpp_f64<DPP_XOR1>(send);
+    }
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        const double keep = b1 ? r[i + Q] : r[i], send = b1 ? r[i] : r[i + Q];
+        q[i] = keep + dpp_f64<DPP_XOR2>(send);
+    }
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        q[i] += dpp_f64<0x124>(q[i]);  // row_ror:4  (lanes of one class inside a 16-lane row)
+        q[i] += dpp_f64<0x128>(q[i]);  // row_ror:8
+        q[i] += bperm_f64(q[i], lane ^ 16);
+        q[i] += bperm_f64(q[i], lane ^ 32);
+    }
+#pragma unroll
+    for (int w = 0; w < NV; ++w) {
+        const int wb0 = w / H, rem = w % H, wb1 = rem / Q, i = rem % Q;
+        out[w] = readlane_f64(q[i], wb0 + 2 * wb1);
+    }
+}
+
 // rows p.. move up by one (row r takes row r+1) in a per-row register pair
 template <int SL>
 __device__ __forceinline__ void shift_up(double (&v)[2], int p) {
@@ -620,18 +656,19 @@ __device__ __forceinline__ void gg_rank1(const WLds &L, double sign) {
 // delta_i / sqrt(K + 1).  The delta_i^2 are the pivots of the LDL' factorisation of the Gram matrix X X' of the
 // active rows: when every pivot exceeds its threshold (orders of magnitude above both tol^2 (K+1) and the rounding of
 // the kept Gram matrix) no row can be purged and the filter's result is "all rows kept" -- exactly, without running
-// it.  Lane i holds row i of the W0 x W0 Gram matrix of the active rows (row-id order, ids in L.ra).
+// it.  The Gram matrix is taken over the columns of AE alone: the right-hand side column can only enlarge every
+// distance, and without it the certificate depends on (E, F) only -- and its pivots can only GROW when a column is
+// appended to F or a row leaves E, so a certificate stays valid across such passes (WState::certMask).
+// Lane i holds row i of the W0 x W0 Gram matrix of the active rows (row-id order, ids in L.ra).
 template <int WM>
-__device__ __forceinline__ bool full_rank_certified(const WLds &L, double bEv, int W0) {
+__device__ __forceinline__ bool full_rank_certified(const WLds &L, int W0) {
     const int lane = lane_id();
     const int ri = L.ra[lane < W0 ? lane : 0];
-    const double bei = bperm_f64(bEv, ri);
     double a[WM];
 #pragma unroll
     for (int c = 0; c < WM; ++c) {
         const int rc = L.ra[c < W0 ? c : 0];
-        const double bec = readlane_f64(bEv, rc);
-        const double v = fma(bei, bec, L.GG[ri * MJX + rc]);
+        const double v = L.GG[ri * MJX + rc];
         a[c] = (lane < W0 && c < W0) ? v : 0.0;
     }
     bool ok = true;
@@ -640,8 +677,7 @@ __device__ __forceinline__ bool full_rank_certified(const WLds &L, double bEv, i
         if (c < W0) {  // uniform
             const double d = readlane_f64(a[c], c);
             const int rc = L.ra[c];
-            const double bec = readlane_f64(bEv, rc);
-            const double thr = fmax(1e-8, 1e-6 * fma(bec, bec, L.GG[rc * MJX + rc]));
+            const double thr = fmax(1e-8, 1e-6 * L.GG[rc * MJX + rc]);
             if (!(d > thr)) ok = false;
             const double r = fast_rcp(d > thr ? d : 1.0);
             const double lic = a[c] * r;
@@ -842,15 +878,23 @@ __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int 
     set_row<SL>(R.dg, K, dnew);
     set_row<SL>(R.rd, K, rdn);
     set_row<SL>(R.cF, K, hj);
-    // border row: y_K,w = x_w - sum_c L(K,c) y_c,w
+    // border row: y_K,w = x_w - sum_c L(K,c) y_c,w  (the twelve sums in one butterfly)
+    double prod[NR], sums[NR];
+#pragma unroll
+    for (int w = 0; w < NR; ++w) {
+        double s = 0.0;
+        if (w < MJ || w == CC) {  // uniform
+#pragma unroll
+            for (int t = 0; t < SL; ++t) s = (lane + KSLOT * t < K) ? fma(lnew[t], R.Y[w][t], s) : s;
+        }
+        prod[w] = s;
+    }
+    wave_sum_multi<NR>(prod, sums);
 #pragma unroll
     for (int w = 0; w < NR; ++w) {
         if (w < MJ || w == CC) {  // uniform
             const double xw = (w == CC) ? hj : readlane_f64(cj, w < MJX ? w : 0);
-            double s = 0.0;
-#pragma unroll
-            for (int t = 0; t < SL; ++t) s = (lane + KSLOT * t < K) ? fma(lnew[t], R.Y[w][t], s) : s;
-            s = wave_sum(s);
+            const double s = sums[w];
             const double yk = xw - s;
             if (dz != 0.0 && w < MJX && lane == 0) {  // t_w = H[w][c] follows the change of c
                 const double hv = fma(dz, s, L.H[w * NR + CC]);
@@ -964,15 +1008,22 @@ __device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p
             msum = fma(fr[t], frd[t], msum);
         }
         const double mpp = wave_sum(msum);
+        double prod[NR], sums[NR];
 #pragma unroll
         for (int w = 0; w < NR; ++w) {
             double s = 0.0;
             if (w < MJ || w == CC) {  // uniform
 #pragma unroll
                 for (int t = 0; t < SL; ++t) s = (lane + KSLOT * t < K) ? fma(R.Y[w][t], frd[t], s) : s;
-                s = wave_sum(s);
             }
-            if (lane == 0) L.yn[w] = s;
+            prod[w] = s;
+        }
+        wave_sum_multi<NR>(prod, sums);
+        {
+            double gv = 0.0;
+#pragma unroll
+            for (int w = 0; w < NR; ++w) gv = (lane == w) ? sums[w] : gv;
+            if (lane < NR) L.yn[lane] = gv;
         }
         wave_sync();
         h_rank1(L, -1.0 / mpp);
@@ -1100,6 +1151,8 @@ struct WState {
     int appJ;                       // variable to append, or -1
     double relDz;                   // the shift of z[appJ] that hq has already followed (0: none)
     double blkDz;                   // the same for the single variable a blocked step sent to a nonzero bound
+    unsigned certMask;              // active-row set the full-rank certificate currently holds for (0: none); cleared
+                                    // by a deletion from F, kept by appends, valid for every subset of its rows
     bool cFstale;                   // R.cF lags behind hq[F] (only full re-sweeps of the border read it)
     bool appAll;                    // append every variable with status IN that has no row (start, after freeK!)
 };
@@ -1128,11 +1181,12 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
     wave_sync();
     if (W0 > 0) {
         // usually the Gram matrix of the active rows proves that the filter cannot purge anything
-        bool certified = false;
-        if (K + 1 >= W0) {
-            if (W0 > 8) certified = full_rank_certified<MJX>(L, S.bEv, W0);
-            else if (W0 > 4) certified = full_rank_certified<8>(L, S.bEv, W0);
-            else certified = full_rank_certified<4>(L, S.bEv, W0);
+        bool certified = (act & ~S.certMask) == 0u;  // (a subset of a certified row set with no column lost since)
+        if (!certified && K >= W0) {
+            if (W0 > 8) certified = full_rank_certified<MJX>(L, W0);
+            else if (W0 > 4) certified = full_rank_certified<8>(L, W0);
+            else certified = full_rank_certified<4>(L, W0);
+            S.certMask = certified ? act : 0u;
         }
         if (!certified) {
             if (SL == 1) kept = rank_filter<1>(R, S.bEv, act, K, tol);
@@ -1544,6 +1598,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
     WPH_DECL;
     const int ndel = __popcll(S.del0) + __popcll(S.del1);
     if (ndel > 0) {
+        S.certMask = 0u;  // (a column of AE goes: the Gram pivots may shrink)
         const bool single = (ndel == 1);
         // A single deletion with one register slot: the border rows follow by a scan and H by the downdate, and when
         // the variable went to a nonzero bound the change of c is folded in beforehand -- no re-gather, no re-sweep.
@@ -1722,6 +1777,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     S.appJ = -1;
     S.relDz = 0.0;
     S.blkDz = 0.0;
+    S.certMask = 0u;
     S.cFstale = false;
     S.appAll = true;
     for (int e = lane; e < NR * NR; e += 64) L.H[e] = 0.0;
