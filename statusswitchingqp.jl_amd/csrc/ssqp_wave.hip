@@ -143,15 +143,44 @@ __device__ __forceinline__ void wave_sum_multi(const double (&v)[NV], double (&o
     }
 }
 
+// lane i takes the value of lane i + 1 (DPP wave_shl:1; lane 63 keeps its own value)
+__device__ __forceinline__ double lane_next_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int lane_next_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xF, 0xF, false); }
+// lane i takes the value of lane i - 1 (DPP wave_shr:1; lane 0 gets `fill`)
+__device__ __forceinline__ double lane_prev_f64(double v, double fill) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, 0x138, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, 0x138, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// one step of an inclusive scan over the 64 lanes: the value of the lane the step combines with, `fill` where there is
+// none.  Steps 0..3: row_shr:1,2,4,8 inside the 16-lane rows; step 4: row_bcast:15 (the last lane of rows 0 and 2 to
+// every lane of rows 1 and 3); step 5: row_bcast:31 (lane 31 to rows 2 and 3).
+template <int STEP>
+__device__ __forceinline__ double scan_src_f64(double v, double fill) {
+    constexpr int ctrl = (STEP == 0) ? 0x111 : (STEP == 1) ? 0x112 : (STEP == 2) ? 0x114 : (STEP == 3) ? 0x118
+                       : (STEP == 4) ? 0x142 : 0x143;
+    constexpr int rowmask = (STEP < 4) ? 0xF : (STEP == 4) ? 0xA : 0xC;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, ctrl, rowmask, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, ctrl, rowmask, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
 // rows p.. move up by one (row r takes row r+1) in a per-row register pair
 template <int SL>
 __device__ __forceinline__ void shift_up(double (&v)[2], int p) {
     const int lane = lane_id();
-    const double n0 = bperm_f64(v[0], (lane + 1) & 63);
+    const double n0 = lane_next_f64(v[0]);
     if (SL == 1) {
         v[0] = (lane >= p) ? n0 : v[0];
     } else {
-        const double n1 = bperm_f64(v[1], (lane + 1) & 63);
+        const double n1 = lane_next_f64(v[1]);
         const double first1 = readlane_f64(v[1], 0);
         const double m0 = (lane == 63) ? first1 : n0;
         v[0] = (lane >= p) ? m0 : v[0];
@@ -161,11 +190,11 @@ __device__ __forceinline__ void shift_up(double (&v)[2], int p) {
 template <int SL>
 __device__ __forceinline__ void shift_up_i(int (&v)[2], int p) {
     const int lane = lane_id();
-    const int n0 = bperm_i(v[0], (lane + 1) & 63);
+    const int n0 = lane_next_i32(v[0]);
     if (SL == 1) {
         v[0] = (lane >= p) ? n0 : v[0];
     } else {
-        const int n1 = bperm_i(v[1], (lane + 1) & 63);
+        const int n1 = lane_next_i32(v[1]);
         const int first1 = __builtin_amdgcn_readlane(v[1], 0);
         const int m0 = (lane == 63) ? first1 : n0;
         v[0] = (lane >= p) ? m0 : v[0];
@@ -418,33 +447,55 @@ __device__ __forceinline__ void delete_update(const Fac &F, Rows &R, int K, int 
 template <int SL>
 __device__ __forceinline__ void delete_compact(const Fac &F, int K, int p) {
     const int lane = lane_id();
-    for (int c = 0; c < p; ++c) {  // columns c < p lose row p: rows r > p move up by one inside the column
-        double a[2];
+    constexpr int CB = 4;  // columns per read / write round (their storage is disjoint)
+    for (int c0 = 0; c0 < p; c0 += CB) {  // columns c < p lose row p: rows r > p move up by one inside the column
+        double a[CB][2];
 #pragma unroll
-        for (int t = 0; t < SL; ++t) {
-            const int rn = lane + KSLOT * t;  // new row
-            a[t] = (rn >= p && rn + 1 < K) ? fac_get<SL>(F, rn + 1, c) : 0.0;
+        for (int u = 0; u < CB; ++u) {
+            const int c = (c0 + u < p) ? c0 + u : c0;
+#pragma unroll
+            for (int t = 0; t < SL; ++t) {
+                const int rn = lane + KSLOT * t;  // new row
+                a[u][t] = (rn >= p && rn + 1 < K) ? fac_get<SL>(F, rn + 1, c) : 0.0;
+            }
         }
         wave_sync();
 #pragma unroll
-        for (int t = 0; t < SL; ++t) {
-            const int rn = lane + KSLOT * t;
-            fac_put<SL>(F, rn, c, a[t], rn >= p && rn + 1 < K);
+        for (int u = 0; u < CB; ++u) {
+            if (c0 + u < p) {  // uniform
+#pragma unroll
+                for (int t = 0; t < SL; ++t) {
+                    const int rn = lane + KSLOT * t;
+                    fac_put<SL>(F, rn, c0 + u, a[u][t], rn >= p && rn + 1 < K);
+                }
+            }
         }
     }
-    for (int c = p + 1; c < K; ++c) {  // column c -> c - 1, rows r > c -> r - 1 (ascending: the target is vacated)
-        double a[2];
+    // column c -> c - 1, rows r > c -> r - 1, ascending: the target of column c is the storage of column c - 1, which
+    // this round (or an earlier one) has already read
+    for (int c0 = p + 1; c0 < K; c0 += CB) {
+        double a[CB][2];
 #pragma unroll
-        for (int t = 0; t < SL; ++t) {
-            const int rn = lane + KSLOT * t;
-            a[t] = (rn >= c && rn + 1 < K) ? fac_get<SL>(F, rn + 1, c) : 0.0;
+        for (int u = 0; u < CB; ++u) {
+            const int c = (c0 + u < K) ? c0 + u : c0;
+#pragma unroll
+            for (int t = 0; t < SL; ++t) {
+                const int rn = lane + KSLOT * t;
+                a[u][t] = (rn >= c && rn + 1 < K) ? fac_get<SL>(F, rn + 1, c) : 0.0;
+            }
         }
         wave_sync();
 #pragma unroll
-        for (int t = 0; t < SL; ++t) {
-            const int rn = lane + KSLOT * t;
-            fac_put<SL>(F, rn, c - 1, a[t], rn >= c && rn + 1 < K);
+        for (int u = 0; u < CB; ++u) {
+            if (c0 + u < K) {  // uniform
+#pragma unroll
+                for (int t = 0; t < SL; ++t) {
+                    const int rn = lane + KSLOT * t;
+                    fac_put<SL>(F, rn, c0 + u - 1, a[u][t], rn >= c0 + u && rn + 1 < K);
+                }
+            }
         }
+        wave_sync();
     }
     wave_sync();
 }
@@ -927,15 +978,14 @@ __device__ __forceinline__ void border_update_scan(Rows &R, int K, int p, const 
                                                    const double (&dgold)[2], int MJ) {
     const int lane = lane_id();
     const bool on = lane > p && lane < K;
+    // inclusive scan of the multipliers; Astep[st] = the multiplier a lane applies to what step st brings in
     double A = on ? dgold[0] * R.rd[0] : 1.0;
     double Astep[6];
-#pragma unroll
-    for (int st = 0; st < 6; ++st) {
-        const int d = 1 << st;
+    sfor<0, 6>(SFOR_BODY(st) {
+        SFOR_IDX(st);
         Astep[st] = A;
-        const double Ap = bperm_f64(A, (lane - d) & 63);
-        A = (lane >= d) ? A * Ap : A;
-    }
+        A = A * scan_src_f64<st>(A, 1.0);
+    });
     const double pk = on ? pv[0] : 0.0, bk = on ? bt[0] : 0.0;
 #pragma unroll
     for (int w = 0; w < NR; ++w) {
@@ -943,14 +993,12 @@ __device__ __forceinline__ void border_update_scan(Rows &R, int K, int p, const 
             const double yp = rbcast<1>(R.Y[w], p);
             const double v = on ? fma(pk, yp, R.Y[w][0]) : 0.0;
             double B = bk * v;
-#pragma unroll
-            for (int st = 0; st < 6; ++st) {
-                const int d = 1 << st;
-                const double Bp = bperm_f64(B, (lane - d) & 63);
-                B = (lane >= d) ? fma(Astep[st], Bp, B) : B;
-            }
-            const double sk = bperm_f64(B, (lane - 1) & 63);  // exclusive: the state before row k
-            R.Y[w][0] = on ? fma(-pk, (lane >= 1) ? sk : 0.0, v) : R.Y[w][0];
+            sfor<0, 6>(SFOR_BODY(st) {
+                SFOR_IDX(st);
+                B = fma(Astep[st], scan_src_f64<st>(B, 0.0), B);
+            });
+            const double sk = lane_prev_f64(B, 0.0);  // exclusive: the state before row k
+            R.Y[w][0] = on ? fma(-pk, sk, v) : R.Y[w][0];
         }
     }
 }
