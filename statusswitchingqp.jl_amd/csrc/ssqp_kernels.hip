@@ -795,9 +795,145 @@ __device__ __forceinline__ bool bordered_ldl1(double *fac, double *rd, int jb, i
 // the rank-4 update to the trailing columns.  Two workgroup barriers per FOUR columns instead of one per
 // column.  Needs R - jb <= 256 (four row slots per lane); otherwise the one-column version runs.
 
+// Blocked right-looking version for ANY size (used above 256 rows, where the factor lives in the workgroup's global
+// arena): PB = 16 columns per panel.
+//   1. one wavefront factors the PB x PB diagonal block in registers (lane = row, v_readlane broadcasts) and leaves the
+//      multipliers m(c2,c) = a(j0+c2, j0+c) / d_c and the reciprocal pivots in LDS;
+//   2. every thread applies those eliminations to its rows below the block (rows are independent: 16 entries in
+//      registers, 120 multiply-adds, one coalesced load/store per column);
+//   3. the trailing matrix (border rows and Schur block included) gets the rank-PB update on the matrix cores: each
+//      16 x 16 tile of C is loaded ONCE, takes four chained v_mfma_f64_16x16x4_f64 (one per 4 panel columns) and is
+//      stored once -- four times the arithmetic intensity of the 4-column panel version.
+// Same storage convention as bordered_ldl1 / bordered_ldl: column j holds the unscaled a(i,j), rd[j] = 1/d_j.
+__device__ __forceinline__ bool bordered_ldl_blocked(double *fac, double *rd, int jb, int je, int R, const Lds &L) {
+    constexpr int PB = 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *mult = L.arena;             // PB x PB multipliers, column-major: mult[c2 + PB*c] (c2 > c)
+    double *prd = L.arena + PB * PB;    // PB reciprocal pivots
+    for (int j0 = jb; j0 < je; j0 += PB) {
+        const int nb = (je - j0 < PB) ? je - j0 : PB;
+        __syncthreads();
+        if (wave == 0) {  // ---- diagonal block: rows j0 .. j0+nb-1 (lane = row of the block)
+            double a[PB];
+#pragma unroll
+            for (int c = 0; c < PB; ++c) {
+                const bool live = (c < nb) && (lane < nb) && (lane >= c);
+                const int jc = j0 + (c < nb ? c : nb - 1);
+                const double v = fac[coloff(jc, R) + (live ? j0 + lane - jc : 0)];
+                a[c] = live ? v : 0.0;
+            }
+            bool ok = true;
+#pragma unroll
+            for (int c = 0; c < PB; ++c) {
+                if (c < nb) {  // uniform
+                    const double d = readlane_f64(a[c], c);
+                    if (!(d > 0.0)) ok = false;
+                    const double r = fast_rcp(d);
+                    if (lane == 0) prd[c] = r;
+#pragma unroll
+                    for (int c2 = c + 1; c2 < PB; ++c2) {
+                        if (c2 < nb) {
+                            const double m = readlane_f64(a[c], c2) * r;  // a(j0+c2, j0+c) / d_c
+                            if (lane == 0) mult[c2 + PB * c] = m;
+                            a[c2] = (lane >= c2) ? fma(-m, a[c], a[c2]) : a[c2];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 1; c < PB; ++c) {
+                const int jc = j0 + c;
+                if (c < nb && lane < nb && lane >= c) fac[coloff(jc, R) + j0 + lane - jc] = a[c];
+            }
+            if (lane == 0) {
+                L.ired[2 * NW + 5] = ok ? 1 : 0;
+#pragma unroll
+                for (int c = 0; c < PB; ++c)
+                    if (c < nb) rd[j0 + c] = prd[c];
+            }
+        }
+        __syncthreads();
+        if (!L.ired[2 * NW + 5]) {
+            __syncthreads();
+            return false;
+        }
+        // ---- rows below the diagonal block: the same eliminations, row by row
+        for (int i = j0 + nb + tid; i < R; i += NT) {
+            double a[PB];
+#pragma unroll
+            for (int c = 0; c < PB; ++c) {
+                const int jc = j0 + (c < nb ? c : nb - 1);
+                a[c] = fac[coloff(jc, R) + i - jc];
+            }
+#pragma unroll
+            for (int c = 0; c < PB; ++c) {
+                if (c < nb) {
+#pragma unroll
+                    for (int c2 = c + 1; c2 < PB; ++c2)
+                        if (c2 < nb) a[c2] = fma(-mult[c2 + PB * c], a[c], a[c2]);
+                }
+            }
+#pragma unroll
+            for (int c = 1; c < PB; ++c)
+                if (c < nb) fac[coloff(j0 + c, R) + i - (j0 + c)] = a[c];
+        }
+        __syncthreads();
+        // ---- rank-nb update of the trailing columns: D = C - A B, A = a(rows, panel), B = (a(cols, panel) / d)'
+        {
+            using f64x4 = __attribute__((ext_vector_type(4))) double;
+            const int jt = j0 + nb;                      // first trailing column
+            const int nt = (R - jt + 15) >> 4;           // tiles per dimension
+            const int kk = lane >> 4, l15 = lane & 15;
+            const int ntile = nt * (nt + 1) / 2;
+            for (int t = wave; t < ntile; t += NW) {
+                int tk = 0, f = t;  // lower-triangular tile index -> (ti >= tk), column-major over tile columns
+                while (f >= nt - tk) {
+                    f -= nt - tk;
+                    ++tk;
+                }
+                const int ti = tk + f;
+                const int i0 = jt + 16 * ti, k0 = jt + 16 * tk;
+                const int ra_ = i0 + l15, cb_ = k0 + l15;
+                const int colc = (cb_ < R) ? cb_ : jt;
+                const int occ = coloff(colc, R) - colc;
+                f64x4 cv;
+                bool ok[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = i0 + kk + 4 * g;
+                    ok[g] = (cb_ < R) && (row < R) && (row >= cb_);
+                    cv[g] = fac[occ + (ok[g] ? row : colc)];
+                    cv[g] = ok[g] ? cv[g] : 0.0;
+                }
+#pragma unroll
+                for (int kb = 0; kb < PB / 4; ++kb) {
+                    const int pc = 4 * kb + kk;          // this lane's panel column in this k-block
+                    const bool live = pc < nb;
+                    const int jc = j0 + (live ? pc : 0);
+                    const int opc = coloff(jc, R) - jc;
+                    const double av = fac[opc + (ra_ < R ? ra_ : jc)];
+                    const double bv = fac[opc + (cb_ < R ? cb_ : jc)];
+                    const double a = (ra_ < R && live) ? -av : 0.0;
+                    const double bb = (cb_ < R && live) ? bv * rd[jc] : 0.0;
+                    if (4 * kb < nb) cv = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, cv, 0, 0, 0);  // uniform
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = i0 + kk + 4 * g;
+                    if (ok[g]) fac[occ + row] = cv[g];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
 __device__ __forceinline__ bool bordered_ldl(double *fac, double *rd, int jb, int je, int R, const Lds &L) {
     constexpr int RS = 4;
-    if (R - jb > 64 * RS) return bordered_ldl1(fac, rd, jb, je, R, L);
+    // above four register slots of rows: the blocked version (the factor is in the global arena there, and the LDS
+    // arena is free for the panel's multipliers)
+    if (R - jb > 64 * RS) return (fac != L.arena) ? bordered_ldl_blocked(fac, rd, jb, je, R, L) : bordered_ldl1(fac, rd, jb, je, R, L);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     SUBPHASE_DECL(tsub);
     for (int j = jb; j < je; j += 4) {
