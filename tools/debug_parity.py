@@ -33,7 +33,7 @@ zo, So, sto, deto, _ = orc.solveQP_warm_batch(prob["V"], prob["A"], prob["G"], p
 bad = np.flatnonzero((res["status"] != sto) | (res["S"] != So).any(axis=1))
 scale = np.maximum(np.abs(zo).max(axis=1), 1e-300)
 rel = (np.abs(res["z"] - zo).max(axis=1) / scale)
-print(name, opts, "nprob", nprob, "bad", len(bad), bad[:20], "paths", np.unique(res["stats"]["path"]), "maxK", res["stats"]["max_k"].max(),
+print(name, opts, "sum_k3 %.4g" % float(res["stats"]["sum_k3"].sum()), "alg_flops %.4g" % float(res["stats"]["alg_flops"].sum()), "nprob", nprob, "bad", len(bad), bad[:20], "paths", np.unique(res["stats"]["path"]), "maxK", res["stats"]["max_k"].max(),
       "max rel z err %.2e" % rel.max(), "kernel ms %.3f wall ms %.3f" % (ctx.last_kernel_ms(), ms), flush=True)
 for p in bad[:3]:
     A = prob["A"][p].reshape(cfg.N, cfg.M).T; G = prob["G"][p].reshape(cfg.N, cfg.J).T
