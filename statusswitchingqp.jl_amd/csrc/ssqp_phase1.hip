@@ -270,14 +270,30 @@ __global__ __launch_bounds__(NT1) void ssqp_phase1_kernel(P1Params P) {
         x[k] = S1[k] == SSQP_UP ? hi[k] : lo[k];
     }
     __syncthreads();
+    // (the column of A1 / of Y a thread works on is pulled into registers first when M0 <= 16: the sums below are
+    //  sequential by construction, and with a dependent global load per term each term would cost a cache round trip)
+    constexpr int MC = 16;
     auto refreshY = [&]() {  // Y[:,k] = invB * A1[:,k] for the nonbasic columns
         for (int k = tid; k < N1; k += NT1) {
             if (!nonbasic[k]) continue;
             const double *ak = A1 + (size_t)k * M0;
-            for (int r = 0; r < M0; ++r) {
-                double s = 0.0;
-                for (int t = 0; t < M0; ++t) s += invB[(size_t)t * M0 + r] * ak[t];
-                Y[(size_t)k * M0 + r] = s;
+            if (M0 <= MC) {
+                double av[MC];
+#pragma unroll
+                for (int t = 0; t < MC; ++t) av[t] = (t < M0) ? ak[t] : 0.0;
+                for (int r = 0; r < M0; ++r) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int t = 0; t < MC; ++t)
+                        if (t < M0) s += invB[(size_t)t * M0 + r] * av[t];
+                    Y[(size_t)k * M0 + r] = s;
+                }
+            } else {
+                for (int r = 0; r < M0; ++r) {
+                    double s = 0.0;
+                    for (int t = 0; t < M0; ++t) s += invB[(size_t)t * M0 + r] * ak[t];
+                    Y[(size_t)k * M0 + r] = s;
+                }
             }
         }
         __syncthreads();
@@ -291,10 +307,21 @@ __global__ __launch_bounds__(NT1) void ssqp_phase1_kernel(P1Params P) {
         const bool bland = loop > N1;
         double best = -INF;
         int bidx = 0x7fffffff;
+        if (tid < M0) acc[tid] = cost[basis[tid]];  // c[basis] (LDS: broadcast reads below)
+        __syncthreads();
         for (int k = tid; k < N1; k += NT1) {
             if (!nonbasic[k]) continue;
             double s = 0.0;
-            for (int r = 0; r < M0; ++r) s += Y[(size_t)k * M0 + r] * cost[basis[r]];
+            if (M0 <= MC) {
+                double yv[MC];
+#pragma unroll
+                for (int r = 0; r < MC; ++r) yv[r] = (r < M0) ? Y[(size_t)k * M0 + r] : 0.0;
+#pragma unroll
+                for (int r = 0; r < MC; ++r)
+                    if (r < M0) s += yv[r] * acc[r];
+            } else {
+                for (int r = 0; r < M0; ++r) s += Y[(size_t)k * M0 + r] * acc[r];
+            }
             double hv = cost[k] - s;
             if (S1[k] == SSQP_DN) hv = -hv;
             if (hv > tol) {
