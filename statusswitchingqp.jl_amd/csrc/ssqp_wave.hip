@@ -893,7 +893,7 @@ __device__ __forceinline__ void recompute_H_all(const WLds &L, const Rows &R, in
 //   y_c += dz * y,   H[w][c] += dz * sum_r Y[w]_r lnew_r  (the same sums the new border row needs).
 template <int SL>
 __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int &K, int j, const double2 (&hq)[NCH],
-                                           const double2 (&zd)[NCH], double dz) {
+                                           const double2 (&zd)[NCH], double dz, double &gz) {
     const int lane = lane_id();
     const int N = C.N, MJ = C.MJ;
     // everything the new row needs from memory is requested before the factor sweep: one round trip, hidden
@@ -921,6 +921,7 @@ __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int 
         R.rank[t] = ((r < K) && (R.ord[t] > j)) ? R.rank[t] + 1 : R.rank[t];
     }
     const double zj = dense_get(zd, j), hj = dense_get(hq, j);
+    gz = (lane < MJ) ? fma(cj, zj, gz) : gz;  // [A;G][:, F] z_F gains the new variable's term
     set_row_i<SL>(R.ord, K, j);
     set_row_i<SL>(R.rank, K, below);
     set_row<SL>(R.zF, K, zj);
@@ -1035,7 +1036,8 @@ __device__ __forceinline__ void fold_block_shift(const WLds &L, Rows &R, int K, 
 // Delete row p (its variable left F).  single: the border rows and H are still those of the current factor, so
 // H follows by the block-inverse downdate; otherwise the caller re-forms H.
 template <int SL>
-__device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p, int MJ, bool downdate, bool scan) {
+__device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p, int MJ, bool downdate, bool scan,
+                                           double &gz) {
     const int lane = lane_id();
     double pv[2], bt[2], rdold[2], dgold[2];
 #pragma unroll
@@ -1088,6 +1090,7 @@ __device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p
             }
         }
         if (lane < 16) L.xn[lane] = xp;
+        gz = fma(-xp, rbcast<SL>(R.zF, p), gz);  // [A;G][:, F] z_F loses the variable's term
         wave_sync();
         gg_rank1(L, -1.0);
         wave_sync();
@@ -1191,6 +1194,7 @@ struct WState {
     unsigned Sp;        // statuses of this lane's 8 variables, 4 bits each
     unsigned Emask;     // active inequalities (bit j: S[N+j] == EO)
     double bEv;         // lane w: bEall_w = rhs_w - ([A;G] zB)_w
+    double gz;          // lane w: ([A;G][:, F] z_F)_w, carried along with z_F (append, delete, blocked and full steps)
     int K;
     int nShift;         // status switches since hq / bEall were last re-evaluated from (z, S)
     bool hbValid, cDirty;
@@ -1323,25 +1327,22 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
                 lmin = fmin(lmin, Lr[t]);
             }
         }
-        // inactive inequalities: zo = g - G z, po = G[:,F] p  (:78-89); the bound part of G z is cached in bEall
-        double lin = INF;  // lane j: ratio of inequality j
+        // inactive inequalities: zo = g - G z, po = G[:,F] p  (:78-89), with NO sum over the free variables: row w of
+        // [A;G] lives in lane w; [A;G][w,F] alpha = -(sum over the kept rows a of H[w][a] alphaL_a + H[w][c]) comes
+        // straight from the kept Schur block (alpha = -V_FF^-1 (AE' alphaL + c)), [A;G][w,F] z_F is carried along
+        // (gz), and the bound part of G z is cached in bEall.
+        double Ga = 0.0;
+        {
+            const int wl = lane < MJ ? lane : 0;
+            Ga = L.H[wl * NR + CC];
 #pragma unroll
-        for (int w = 0; w < MJX; ++w) {
-            if (w >= M && w < MJ && !((S.Emask >> (w - M)) & 1u)) {  // uniform: inactive inequality w - M
-                double sz = 0.0, sp = 0.0;
-#pragma unroll
-                for (int t = 0; t < SL; ++t) {
-                    const int r = lane + KSLOT * t;
-                    sz = (r < K) ? fma(R.X[w][t], R.zF[t], sz) : sz;
-                    sp = (r < K) ? fma(R.X[w][t], p[t], sp) : sp;
-                }
-                sz = wave_sum(sz);
-                sp = wave_sum(sp);
-                const double zo = readlane_f64(S.bEv, w) - sz;
-                const double ratio = (sp > tol) ? zo / sp : INF;  // :85-86
-                lin = (lane == w - M) ? ratio : lin;
-            }
+            for (int a = 0; a < MJX; ++a)
+                if ((kept >> a) & 1u) Ga = fma(L.H[wl * NR + a], L.aLrow[a], Ga);  // uniform
+            Ga = -Ga;
         }
+        const double po = Ga - S.gz, zo = S.bEv - S.gz;
+        const bool inact = lane >= M && lane < MJ && !((S.Emask >> ((lane - M) & 31)) & 1u);
+        const double lin = (inact && po > tol) ? zo / po : INF;  // :85-86  (lane M + j: inequality j)
         lmin = fmin(lmin, lin);
         const double L1 = wave_min(lmin);
         C.sFlops += 2ll * (J - __popc(S.Emask)) * (N + K);
@@ -1350,11 +1351,13 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
             int firstId = 0x7fffffff;
             unsigned long long dm[2] = {0ull, 0ull};
             bool hit[2] = {false, false};
+            double zstep[2] = {0.0, 0.0};  // z_F + L1 p before the snap
 #pragma unroll
             for (int t = 0; t < SL; ++t) {
                 const int r = lane + KSLOT * t;
                 if (r < K) {
                     double zn = R.zF[t] + L1 * p[t];  // :99
+                    zstep[t] = zn;
                     if (Lr[t] < INF && !(Lr[t] - L1 > tol)) {  // :102-116
                         const bool up = p[t] > tol;
                         zn = up ? R.ur[t] : R.dr[t];
@@ -1367,8 +1370,9 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
             }
             const bool ihit = (lin < INF) && !(lin - L1 > tol);
             const unsigned long long im = __ballot(ihit);
-            if (ihit) firstId = min(firstId, N + lane + 1);
-            S.Emask |= (unsigned)im;
+            if (ihit) firstId = min(firstId, N + (lane - M) + 1);
+            S.Emask |= (unsigned)(im >> M);
+            S.gz = (lane < MJ) ? fma(L1, po, S.gz) : S.gz;  // z_F += L1 p
             // the switched variables: statuses, z of the bound set, and the caches hq / bEall follow
 #pragma unroll
             for (int t = 0; t < SL; ++t) {
@@ -1379,6 +1383,16 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
                     const int jv = __builtin_amdgcn_readlane(R.ord[t], l);
                     const double pj = readlane_f64(p[t], l);
                     const double zn = readlane_f64(R.zF[t], l);
+                    {   // (the variable was snapped to its bound: gz follows the exact value of z_F)
+                        const double dzs = zn - readlane_f64(zstep[t], l);
+#pragma unroll
+                        for (int w = 0; w < MJX; ++w) {
+                            if (w < MJ) {
+                                const double xw = readlane_f64(R.X[w][t], l);
+                                S.gz = (lane == w) ? fma(xw, dzs, S.gz) : S.gz;
+                            }
+                        }
+                    }
                     st_set(S.Sp, jv, (pj > tol) ? SSQP_UP : SSQP_DN);
                     dense_set(S.zd, jv, zn);
                     if (zn != 0.0) {
@@ -1413,6 +1427,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
             const int r = lane + KSLOT * t;
             R.zF[t] = (r < K) ? alpha[t] : R.zF[t];
         }
+        S.gz = (lane < MJ) ? Ga : S.gz;
     }
 
     WPH(6);  // full step bookkeeping
@@ -1657,7 +1672,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
                 fold_block_shift<SL>(L, R, S.K, pl, MJ, S.blkDz);
                 S.cFstale = true;
             }
-            delete_var<SL>(L, R, S.K, pl, MJ, true, true);
+            delete_var<SL>(L, R, S.K, pl, MJ, true, true, S.gz);
             S.del0 = S.del1 = 0ull;
             S.cDirty = false;
             S.blkDz = 0.0;
@@ -1674,7 +1689,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
             while (dm) {
                 const int pl = 63 - __clzll(dm);
                 dm &= ~(1ull << pl);
-                delete_var<SL>(L, R, S.K, pl + KSLOT, MJ, single, false);
+                delete_var<SL>(L, R, S.K, pl + KSLOT, MJ, single, false, S.gz);
             }
         }
         {
@@ -1682,7 +1697,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
             while (dm) {
                 const int pl = 63 - __clzll(dm);
                 dm &= ~(1ull << pl);
-                delete_var<SL>(L, R, S.K, pl, MJ, single, false);
+                delete_var<SL>(L, R, S.K, pl, MJ, single, false, S.gz);
             }
         }
         WPH(10);  // deletes (update + downdate + compaction + shifts)
@@ -1721,7 +1736,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
         S.relDz = 0.0;
         if (S.appJ >= 0) {
             if (S.K + 1 > C.RC) return W_HANDOVER;
-            if (!append_var<SL>(C, L, R, S.K, S.appJ, S.hq, S.zd, dzFold)) {
+            if (!append_var<SL>(C, L, R, S.K, S.appJ, S.hq, S.zd, dzFold, S.gz)) {
                 C.ret = -1;
                 C.det = SSQP_DETAIL_POSDEF_V;
                 return W_BREAK;
@@ -1744,7 +1759,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
                             const int jv = 2 * l + 128 * m + e;
                             // (variables that already have a row are not in this state: the factor is empty)
                             if (S.K + 1 > C.RC || S.K + 1 > 64 * SL - 1) return W_HANDOVER;
-                            if (!append_var<SL>(C, L, R, S.K, jv, S.hq, S.zd, 0.0)) {
+                            if (!append_var<SL>(C, L, R, S.K, jv, S.hq, S.zd, 0.0, S.gz)) {
                                 C.ret = -1;
                                 C.det = SSQP_DETAIL_POSDEF_V;
                                 return W_BREAK;
@@ -1817,6 +1832,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
         S.Emask = (unsigned)__ballot(sj == SSQP_EO);
     }
     S.bEv = 0.0;
+    S.gz = 0.0;
     S.K = 0;
     S.hbValid = false;
     S.cDirty = false;
