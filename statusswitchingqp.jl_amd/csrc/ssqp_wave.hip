@@ -283,13 +283,15 @@ struct Rows {  // one entry per row of the kept factor = per free variable, row 
     int ord[2], rank[2];         // variable index; its rank among the free variables by index (findall order)
     double zF[2], ur[2], dr[2];  // z, upper and lower bound of the variable
     double dg[2], rd[2];         // pivot d_r of the LDL' factor and its reciprocal
-    double cF[2];                // c_r = hq[ord_r]  (SSQP.jl:324)
-    double X[MJX][2];            // column ord_r of [A;G]: X[w] = [A;G][w, ord_r]
     double Y[NR][2];             // forward-substituted border: Y[w] = (L^-1 [A;G][w,F]')_r, Y[CC] = (L^-1 c)_r
 };
 
 struct WLds {
     Fac F;
+    // (the columns of [A;G] of the free variables, X[w]_r = [A;G][w, ord_r], are NOT kept in registers: the hot path
+    //  never needs them -- the ratio test works from H and gz, the Gram matrix and gz take the column of a variable
+    //  when it is appended or deleted -- and the rare paths (rank filter run in full, purged-row least squares,
+    //  polishSz!) gather them from Ct)
     double *H;      // NR x NR, symmetric, full: H[a][b] = sum_r Y[a]_r Y[b]_r / d_r
     double *Hs;     // W x W gathered block for the lambda solve
     double *tr;     // scratch of small_spd_solve
@@ -300,6 +302,20 @@ struct WLds {
     double *xn;     // 16 doubles: a column of [A;G] (for the rank-1 change of GG)
     int16_t *ra;    // kept row ids in order
 };
+
+// [A;G][w, ord_r] for this lane's rows (a gather from the contiguous row w of Ct; cold paths only)
+template <int SL>
+__device__ __forceinline__ void gather_X(const double *__restrict__ Ct, int N, int w, const int (&ord)[2], int K,
+                                         double (&x)[2]) {
+    const int lane = lane_id();
+    x[0] = x[1] = 0.0;
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int r = lane + KSLOT * t;
+        const double v = Ct[(size_t)w * N + (r < K ? ord[t] : 0)];
+        x[t] = (r < K) ? v : 0.0;
+    }
+}
 
 // one column of the factor for this lane's rows, zero where there is no entry (rows <= c, rows >= K, !valid)
 template <int SL>
@@ -502,16 +518,24 @@ __device__ __forceinline__ void delete_compact(const Fac &F, int K, int p) {
 
 // forward substitution L y = b of the border columns selected by `cols` (bit w), from their raw right-hand sides
 template <int SL>
-__device__ __forceinline__ void border_sweep(const Fac &F, Rows &R, int K, unsigned cols) {
+__device__ __forceinline__ void border_sweep(const Fac &F, Rows &R, int K, unsigned cols, const double *__restrict__ Ct,
+                                             int N, const double2 (&hq)[NCH]) {
     const int lane = lane_id();
 #pragma unroll
     for (int w = 0; w < NR; ++w) {
         if ((cols >> w) & 1u) {  // uniform
+            if (w == CC) {
 #pragma unroll
-            for (int t = 0; t < SL; ++t) {
-                const int r = lane + KSLOT * t;
-                const double raw = (w == CC) ? R.cF[t] : R.X[w < MJX ? w : 0][t];
-                R.Y[w][t] = (r < K) ? raw : 0.0;
+                for (int t = 0; t < SL; ++t) {
+                    const int r = lane + KSLOT * t;
+                    const double v = dense_gather(hq, (r < K) ? R.ord[t] : 0);  // c = hq[F]  (SSQP.jl:324)
+                    R.Y[w][t] = (r < K) ? v : 0.0;
+                }
+            } else {
+                double x[2];
+                gather_X<SL>(Ct, N, w < MJX ? w : 0, R.ord, K, x);
+#pragma unroll
+                for (int t = 0; t < SL; ++t) R.Y[w][t] = x[t];
             }
         }
     }
@@ -596,7 +620,8 @@ __device__ __forceinline__ void back_sweep(const Fac &F, int K, double (&v)[2]) 
 // as in the reference, operation for operation (IEEE division, multiply and subtract rounded separately).
 // Returns the kept rows as a bit mask over row ids.
 template <int CS>
-__device__ __forceinline__ unsigned rank_filter(const Rows &R, double bEv, unsigned act, int K, double tol) {
+__device__ __forceinline__ unsigned rank_filter(const Rows &R, double bEv, unsigned act, int K, double tol,
+                                                const double *__restrict__ Ct, int N) {
     const int lane = lane_id();
     const int nc = K + 1;
     double x[MJX][CS];
@@ -608,7 +633,9 @@ __device__ __forceinline__ unsigned rank_filter(const Rows &R, double bEv, unsig
         sfor<0, MJX>(SFOR_BODY(i) {
             SFOR_IDX(i);
             const double be = readlane_f64(bEv, i);
-            x[i][cs] = (t < K) ? R.X[i][cs] : ((t == K) ? be : 0.0);
+            double xv = 0.0;
+            if ((act >> i) & 1u) xv = Ct[(size_t)i * N + (t < K ? R.ord[cs] : 0)];  // uniform branch; [A;G][i, ord]
+            x[i][cs] = (t < K) ? xv : ((t == K) ? be : 0.0);
         });
     });
     unsigned kept = 0;
@@ -893,12 +920,13 @@ __device__ __forceinline__ void recompute_H_all(const WLds &L, const Rows &R, in
 //   y_c += dz * y,   H[w][c] += dz * sum_r Y[w]_r lnew_r  (the same sums the new border row needs).
 template <int SL>
 __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int &K, int j, const double2 (&hq)[NCH],
-                                           const double2 (&zd)[NCH], double dz, double &gz) {
+                                           const double *zg, double dz, double &gz) {
     const int lane = lane_id();
     const int N = C.N, MJ = C.MJ;
     // everything the new row needs from memory is requested before the factor sweep: one round trip, hidden
     const double cj = C.Ct[(size_t)(lane < MJ ? lane : 0) * N + j];  // column j of [A;G], row w in lane w
     const double uj = C.uhi[j], dj = C.dlo[j];
+    const double zj = __hip_atomic_load(zg + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (written by this wavefront earlier)
     double lnew[2], vraw[2], ysub[2];
     const double dnew = append_row<SL>(L.F, R, K, j, C.V, N, lnew, vraw, ysub);
     if (!(dnew > 0.0)) return false;
@@ -907,7 +935,6 @@ __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int 
         for (int t = 0; t < SL; ++t) {
             const int r = lane + KSLOT * t;
             R.Y[CC][t] = (r < K) ? fma(dz, ysub[t], R.Y[CC][t]) : R.Y[CC][t];
-            R.cF[t] = (r < K) ? fma(dz, vraw[t], R.cF[t]) : R.cF[t];
         }
     }
     const double rdn = fast_rcp(dnew);
@@ -920,7 +947,7 @@ __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int 
         below += __popcll(__ballot(lt));
         R.rank[t] = ((r < K) && (R.ord[t] > j)) ? R.rank[t] + 1 : R.rank[t];
     }
-    const double zj = dense_get(zd, j), hj = dense_get(hq, j);
+    const double hj = dense_get(hq, j);
     gz = (lane < MJ) ? fma(cj, zj, gz) : gz;  // [A;G][:, F] z_F gains the new variable's term
     set_row_i<SL>(R.ord, K, j);
     set_row_i<SL>(R.rank, K, below);
@@ -929,7 +956,6 @@ __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int 
     set_row<SL>(R.dr, K, dj);
     set_row<SL>(R.dg, K, dnew);
     set_row<SL>(R.rd, K, rdn);
-    set_row<SL>(R.cF, K, hj);
     // border row: y_K,w = x_w - sum_c L(K,c) y_c,w  (the twelve sums in one butterfly)
     double prod[NR], sums[NR];
 #pragma unroll
@@ -953,7 +979,6 @@ __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int 
                 L.H[w * NR + CC] = hv;
                 L.H[CC * NR + w] = hv;
             }
-            if (w < MJX) set_row<SL>(R.X[w < MJX ? w : 0], K, xw);
             set_row<SL>(R.Y[w], K, yk);
             if (lane == 0) L.yn[w] = yk;
         } else if (lane == 0) {
@@ -1008,7 +1033,7 @@ __device__ __forceinline__ void border_update_scan(Rows &R, int K, int p, const 
 // to date).  V[F, j] is column p of V_FF = L D L', so L^-1 V[F, j] = D L' e_p: the border column y_c and t = H[:, c]
 // follow from row p of the factor (before the row is deleted):  y_c,r += dz d_r L(p,r) (r <= p),  H[w][c] += dz X[w]_p.
 template <int SL>
-__device__ __forceinline__ void fold_block_shift(const WLds &L, Rows &R, int K, int p, int MJ, double dz) {
+__device__ __forceinline__ void fold_block_shift(const WLds &L, Rows &R, int K, int p, int MJ, double dz, double xp) {
     const int lane = lane_id();
     double lrow[2];
     load_rowT<SL>(L.F, p, lrow);
@@ -1018,16 +1043,10 @@ __device__ __forceinline__ void fold_block_shift(const WLds &L, Rows &R, int K, 
         const double lr = (r == p) ? 1.0 : ((r < p) ? lrow[t] : 0.0);
         R.Y[CC][t] = (r <= p) ? fma(dz * R.dg[t], lr, R.Y[CC][t]) : R.Y[CC][t];
     }
-#pragma unroll
-    for (int w = 0; w < MJX; ++w) {
-        if (w < MJ) {  // uniform
-            const double xw = rbcast<SL>(R.X[w], p);
-            if (lane == 0) {
-                const double hv = fma(dz, xw, L.H[w * NR + CC]);
-                L.H[w * NR + CC] = hv;
-                L.H[CC * NR + w] = hv;
-            }
-        }
+    if (lane < MJ) {  // lane w: xp = [A;G][w, j]
+        const double hv = fma(dz, xp, L.H[lane * NR + CC]);
+        L.H[lane * NR + CC] = hv;
+        L.H[CC * NR + lane] = hv;
     }
     wave_sync();
     (void)K;
@@ -1037,7 +1056,7 @@ __device__ __forceinline__ void fold_block_shift(const WLds &L, Rows &R, int K, 
 // H follows by the block-inverse downdate; otherwise the caller re-forms H.
 template <int SL>
 __device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p, int MJ, bool downdate, bool scan,
-                                           double &gz) {
+                                           double &gz, double xp) {
     const int lane = lane_id();
     double pv[2], bt[2], rdold[2], dgold[2];
 #pragma unroll
@@ -1080,16 +1099,8 @@ __device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p
         wave_sync();
     }
     if (SL == 1 && scan) border_update_scan(R, K, p, pv, bt, dgold, MJ);  // (after the downdate: that one needs the old rows)
-    {   // the Gram matrix of the rows of [A;G][:, F] loses the column of the deleted variable
-        double xp = 0.0;
-#pragma unroll
-        for (int w = 0; w < MJX; ++w) {
-            if (w < MJ) {
-                const double xw = rbcast<SL>(R.X[w], p);
-                xp = (lane == w) ? xw : xp;
-            }
-        }
-        if (lane < 16) L.xn[lane] = xp;
+    {   // the Gram matrix of the rows of [A;G][:, F] loses the column of the deleted variable (xp: lane w = [A;G][w, j])
+        if (lane < 16) L.xn[lane] = (lane < MJ) ? xp : 0.0;
         gz = fma(-xp, rbcast<SL>(R.zF, p), gz);  // [A;G][:, F] z_F loses the variable's term
         wave_sync();
         gg_rank1(L, -1.0);
@@ -1105,10 +1116,6 @@ __device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p
     shift_up<SL>(R.dr, p);
     shift_up<SL>(R.dg, p);
     shift_up<SL>(R.rd, p);
-    shift_up<SL>(R.cF, p);
-#pragma unroll
-    for (int w = 0; w < MJX; ++w)
-        if (w < MJ) shift_up<SL>(R.X[w], p);
     if (SL == 1 && scan) {
 #pragma unroll
         for (int w = 0; w < NR; ++w)
@@ -1123,7 +1130,7 @@ __device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p
 }
 
 // hq = q + sum over the bound variables with z != 0 of V[:,i] z_i;  bEall = rhs - [A;G] zB   (SSQP.jl:295,324)
-__device__ __forceinline__ void refresh_caches(WCtx &C, double2 (&hq)[NCH], double &bEv, const double2 (&zd)[NCH],
+__device__ __forceinline__ void refresh_caches(WCtx &C, double2 (&hq)[NCH], double &bEv, const double *zg,
                                                unsigned Sp) {
     const int lane = lane_id();
     const int N = C.N, MJ = C.MJ;
@@ -1137,8 +1144,10 @@ __device__ __forceinline__ void refresh_caches(WCtx &C, double2 (&hq)[NCH], doub
 #pragma unroll
     for (int m = 0; m < NCH; ++m) {
         const int r = 2 * lane + 128 * m;
-        zb[m].x = (r < N && st_of(Sp, 2 * m) != SSQP_IN) ? zd[m].x : 0.0;
-        zb[m].y = (r < N && st_of(Sp, 2 * m + 1) != SSQP_IN) ? zd[m].y : 0.0;
+        const double zx = __hip_atomic_load(zg + (r < N ? r : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double zy = __hip_atomic_load(zg + (r < N ? r + 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        zb[m].x = (r < N && st_of(Sp, 2 * m) != SSQP_IN) ? zx : 0.0;
+        zb[m].y = (r < N && st_of(Sp, 2 * m + 1) != SSQP_IN) ? zy : 0.0;
     }
     int ncol = 0;
 #pragma unroll
@@ -1176,21 +1185,12 @@ __device__ __forceinline__ void refresh_caches(WCtx &C, double2 (&hq)[NCH], doub
     C.sRead += 8ll * N * (ncol + MJ + 1);
 }
 
-template <int SL>
-__device__ __forceinline__ void regather_c(Rows &R, int K, const double2 (&hq)[NCH]) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int t = 0; t < SL; ++t) {
-        const int r = lane + KSLOT * t;
-        const double v = dense_gather(hq, (r < K) ? R.ord[t] : 0);
-        R.cF[t] = (r < K) ? v : 0.0;
-    }
-}
-
 // The per-QP state that lives across passes
 struct WState {
     Rows R;
-    double2 hq[NCH], zd[NCH];
+    double2 hq[NCH];
+    double *zg;         // z of this QP in global memory (the output array): the live copy for the BOUND variables
+                        // (x0 at the start, the bound a variable was snapped to since); free variables: R.zF
     unsigned Sp;        // statuses of this lane's 8 variables, 4 bits each
     unsigned Emask;     // active inequalities (bit j: S[N+j] == EO)
     double bEv;         // lane w: bEall_w = rhs_w - ([A;G] zB)_w
@@ -1205,7 +1205,6 @@ struct WState {
     double blkDz;                   // the same for the single variable a blocked step sent to a nonzero bound
     unsigned certMask;              // active-row set the full-rank certificate currently holds for (0: none); cleared
                                     // by a deletion from F, kept by appends, valid for every subset of its rows
-    bool cFstale;                   // R.cF lags behind hq[F] (only full re-sweeps of the border read it)
     bool appAll;                    // append every variable with status IN that has no row (start, after freeK!)
 };
 
@@ -1241,8 +1240,8 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
             S.certMask = certified ? act : 0u;
         }
         if (!certified) {
-            if (SL == 1) kept = rank_filter<1>(R, S.bEv, act, K, tol);
-            else kept = rank_filter<2>(R, S.bEv, act, K, tol);
+            if (SL == 1) kept = rank_filter<1>(R, S.bEv, act, K, tol, C.Ct, N);
+            else kept = rank_filter<2>(R, S.bEv, act, K, tol, C.Ct, N);
             if (kept != act) {
                 const unsigned below = kept & ((1u << (lane & 31)) - 1u);
                 if (lane < MJX && ((kept >> lane) & 1u)) L.ra[__popc(below)] = (int16_t)lane;
@@ -1383,18 +1382,16 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
                     const int jv = __builtin_amdgcn_readlane(R.ord[t], l);
                     const double pj = readlane_f64(p[t], l);
                     const double zn = readlane_f64(R.zF[t], l);
-                    {   // (the variable was snapped to its bound: gz follows the exact value of z_F)
+                    {   // the variable was snapped to its bound: gz follows the exact value of z_F (a rounding-sized
+                        // difference for the variable that set the step length is not worth a memory access)
                         const double dzs = zn - readlane_f64(zstep[t], l);
-#pragma unroll
-                        for (int w = 0; w < MJX; ++w) {
-                            if (w < MJ) {
-                                const double xw = readlane_f64(R.X[w][t], l);
-                                S.gz = (lane == w) ? fma(xw, dzs, S.gz) : S.gz;
-                            }
+                        if (fabs(dzs) > 0x1.0p-44 * fmax(1.0, fabs(zn))) {  // uniform
+                            const double cjv = C.Ct[(size_t)(lane < MJ ? lane : 0) * N + jv];
+                            S.gz = (lane < MJ) ? fma(cjv, dzs, S.gz) : S.gz;
                         }
                     }
                     st_set(S.Sp, jv, (pj > tol) ? SSQP_UP : SSQP_DN);
-                    dense_set(S.zd, jv, zn);
+                    if (lane == 0) S.zg[jv] = zn;
                     if (zn != 0.0) {
                         bound_shift(C, S.hq, S.bEv, jv, zn);
                         S.nShift += 1;
@@ -1515,10 +1512,12 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
 #pragma unroll
                 for (int w = 0; w < MJX; ++w) {
                     if ((kept >> w) & 1u) {
+                        double xw[2];
+                        gather_X<SL>(C.Ct, N, w, R.ord, K, xw);
 #pragma unroll
                         for (int t = 0; t < SL; ++t) {
                             const int r = lane + KSLOT * t;
-                            if (r < K) Q[r + (size_t)K * wi] = R.X[w][t];
+                            if (r < K) Q[r + (size_t)K * wi] = xw[t];
                         }
                         wi += 1;
                     }
@@ -1551,12 +1550,14 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
                     if ((kept >> w) & 1u) {
                         Lda = L.aLrow[w];
                     } else {
+                        double xw[2];
+                        gather_X<SL>(C.Ct, N, w, R.ord, K, xw);
                         for (int c = 0; c < W; ++c) {  // yq = Q' gv
                             double s = 0.0;
 #pragma unroll
                             for (int t = 0; t < SL; ++t) {
                                 const int r = lane + KSLOT * t;
-                                if (r < K) s = fma(Q[r + (size_t)K * c], R.X[w][t], s);
+                                if (r < K) s = fma(Q[r + (size_t)K * c], xw[t], s);
                             }
                             s = wave_sum(s);
                             if (lane == 0) yv[c] = s;
@@ -1585,7 +1586,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
         if (ev.ord < N) {
             const int jv = ev.ord;
             st_set(S.Sp, jv, SSQP_IN);
-            const double zr = dense_get(S.zd, jv);
+            const double zr = __hip_atomic_load(S.zg + jv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             S.relDz = 0.0;
             if (zr != 0.0) {  // B loses a column with a nonzero weight
                 bound_shift(C, S.hq, S.bEv, jv, -zr);
@@ -1634,11 +1635,12 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
 #pragma unroll
         for (int w = 0; w < MJX; ++w) {
             if (w >= M && w < MJ) {  // S[N+j] = |g_j - G[j,:] z| < tol ? EO : OE   (:28-30)
-                double sz = 0.0;
+                double sz = 0.0, xw[2];
+                gather_X<SL>(C.Ct, N, w, R.ord, K, xw);
 #pragma unroll
                 for (int t = 0; t < SL; ++t) {
                     const int r = lane + KSLOT * t;
-                    sz = (r < K) ? fma(R.X[w][t], R.zF[t], sz) : sz;
+                    sz = (r < K) ? fma(xw[t], R.zF[t], sz) : sz;
                 }
                 sz = wave_sum(sz);
                 const double res = readlane_f64(S.bEv, w) - sz;
@@ -1668,11 +1670,10 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
         const bool fast = single && SL == 1 && (!S.cDirty || S.blkDz != 0.0);
         if (fast) {
             const int pl = 63 - __clzll(S.del0);
-            if (S.cDirty) {
-                fold_block_shift<SL>(L, R, S.K, pl, MJ, S.blkDz);
-                S.cFstale = true;
-            }
-            delete_var<SL>(L, R, S.K, pl, MJ, true, true, S.gz);
+            const int jp = rbcast_i<SL>(R.ord, pl);
+            const double xp = C.Ct[(size_t)(lane < MJ ? lane : 0) * C.N + jp];  // lane w: [A;G][w, jp] (used after the update)
+            if (S.cDirty) fold_block_shift<SL>(L, R, S.K, pl, MJ, S.blkDz, xp);
+            delete_var<SL>(L, R, S.K, pl, MJ, true, true, S.gz, xp);
             S.del0 = S.del1 = 0ull;
             S.cDirty = false;
             S.blkDz = 0.0;
@@ -1689,7 +1690,9 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
             while (dm) {
                 const int pl = 63 - __clzll(dm);
                 dm &= ~(1ull << pl);
-                delete_var<SL>(L, R, S.K, pl + KSLOT, MJ, single, false, S.gz);
+                const int jp = rbcast_i<SL>(R.ord, pl + KSLOT);
+                const double xp = C.Ct[(size_t)(lane < MJ ? lane : 0) * C.N + jp];
+                delete_var<SL>(L, R, S.K, pl + KSLOT, MJ, single, false, S.gz, xp);
             }
         }
         {
@@ -1697,17 +1700,17 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
             while (dm) {
                 const int pl = 63 - __clzll(dm);
                 dm &= ~(1ull << pl);
-                delete_var<SL>(L, R, S.K, pl, MJ, single, false, S.gz);
+                const int jp = rbcast_i<SL>(R.ord, pl);
+                const double xp = C.Ct[(size_t)(lane < MJ ? lane : 0) * C.N + jp];
+                delete_var<SL>(L, R, S.K, pl, MJ, single, false, S.gz, xp);
             }
         }
         WPH(10);  // deletes (update + downdate + compaction + shifts)
         S.del0 = S.del1 = 0ull;
         S.blkDz = 0.0;
         if (S.K > 0) {
-            if (S.cDirty || S.cFstale) regather_c<SL>(R, S.K, S.hq);
-            S.cFstale = false;
             const unsigned cols = ((1u << MJ) - 1u) | (1u << CC);
-            border_sweep<SL>(L.F, R, S.K, cols);
+            border_sweep<SL>(L.F, R, S.K, cols, C.Ct, C.N, S.hq);
             if (!single) recompute_H_all<SL>(L, R, S.K, MJ);
             else if (S.cDirty) recompute_H_c<SL>(L, R, S.K, MJ);
             S.cDirty = false;
@@ -1725,9 +1728,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
             if (S.appJ >= 0 && S.relDz != 0.0) {
                 dzFold = S.relDz;  // ... by the released variable's column only: folded into its append
             } else {
-                regather_c<SL>(R, S.K, S.hq);
-                S.cFstale = false;
-                border_sweep<SL>(L.F, R, S.K, 1u << CC);
+                border_sweep<SL>(L.F, R, S.K, 1u << CC, C.Ct, C.N, S.hq);
                 recompute_H_c<SL>(L, R, S.K, MJ);
             }
         }
@@ -1736,7 +1737,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
         S.relDz = 0.0;
         if (S.appJ >= 0) {
             if (S.K + 1 > C.RC) return W_HANDOVER;
-            if (!append_var<SL>(C, L, R, S.K, S.appJ, S.hq, S.zd, dzFold, S.gz)) {
+            if (!append_var<SL>(C, L, R, S.K, S.appJ, S.hq, S.zg, dzFold, S.gz)) {
                 C.ret = -1;
                 C.det = SSQP_DETAIL_POSDEF_V;
                 return W_BREAK;
@@ -1759,7 +1760,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
                             const int jv = 2 * l + 128 * m + e;
                             // (variables that already have a row are not in this state: the factor is empty)
                             if (S.K + 1 > C.RC || S.K + 1 > 64 * SL - 1) return W_HANDOVER;
-                            if (!append_var<SL>(C, L, R, S.K, jv, S.hq, S.zd, 0.0, S.gz)) {
+                            if (!append_var<SL>(C, L, R, S.K, jv, S.hq, S.zg, 0.0, S.gz)) {
                                 C.ret = -1;
                                 C.det = SSQP_DETAIL_POSDEF_V;
                                 return W_BREAK;
@@ -1770,8 +1771,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
             }
         }
     } else if (S.cDirty && S.K > 0) {  // only hq changed (cannot happen without a change of F today; kept for safety)
-        regather_c<SL>(R, S.K, S.hq);
-        border_sweep<SL>(L.F, R, S.K, 1u << CC);
+        border_sweep<SL>(L.F, R, S.K, 1u << CC, C.Ct, C.N, S.hq);
         recompute_H_c<SL>(L, R, S.K, MJ);
         S.cDirty = false;
     }
@@ -1807,13 +1807,12 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     const double tol = P.tol;
 
     WState S;
+    S.zg = P.z + (size_t)prob * N;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         S.R.ord[t] = 0; S.R.rank[t] = 0;
         S.R.zF[t] = S.R.ur[t] = S.R.dr[t] = 0.0;
-        S.R.dg[t] = 1.0; S.R.rd[t] = 1.0; S.R.cF[t] = 0.0;
-#pragma unroll
-        for (int w = 0; w < MJX; ++w) S.R.X[w][t] = 0.0;
+        S.R.dg[t] = 1.0; S.R.rd[t] = 1.0;
 #pragma unroll
         for (int w = 0; w < NR; ++w) S.R.Y[w][t] = 0.0;
     }
@@ -1821,7 +1820,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
 #pragma unroll
     for (int m = 0; m < NCH; ++m) {
         const int r = 2 * lane + 128 * m;
-        S.zd[m] = (r < N) ? *reinterpret_cast<const double2 *>(P.x0 + (size_t)prob * N + r) : make_double2(0.0, 0.0);
+        if (r < N) *reinterpret_cast<double2 *>(S.zg + r) = *reinterpret_cast<const double2 *>(P.x0 + (size_t)prob * N + r);
         const int s0 = (r < N) ? Sg[r] : SSQP_DN, s1 = (r < N) ? Sg[r + 1] : SSQP_DN;
         S.Sp |= ((unsigned)s0 & 15u) << (8 * m);
         S.Sp |= ((unsigned)s1 & 15u) << (8 * m + 4);
@@ -1842,7 +1841,6 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     S.relDz = 0.0;
     S.blkDz = 0.0;
     S.certMask = 0u;
-    S.cFstale = false;
     S.appAll = true;
     for (int e = lane; e < NR * NR; e += 64) L.H[e] = 0.0;
     for (int e = lane; e < MJX * MJX; e += 64) L.GG[e] = 0.0;
@@ -1864,7 +1862,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
             S.nShift = 0;
             S.relDz = 0.0;  // (the re-evaluation changes c for every row: the full refresh runs)
             S.blkDz = 0.0;
-            refresh_caches(C, S.hq, S.bEv, S.zd, S.Sp);
+            refresh_caches(C, S.hq, S.bEv, S.zg, S.Sp);
             S.hbValid = true;
             S.cDirty = true;
         }
@@ -1936,20 +1934,23 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
 
     // ---- results: z (free variables from their rows, bound ones from the dense copy / the bounds), S, status
     const bool polished = (C.ret > 0) && (S.K > 0);
-    double *zg = P.z + (size_t)prob * N;
+    double *zg = S.zg;
+    wave_sync();
 #pragma unroll
     for (int m = 0; m < NCH; ++m) {
         const int r = 2 * lane + 128 * m;
         if (r < N) {
-            double2 zz = S.zd[m];
             const int s0 = st_of(S.Sp, 2 * m), s1 = st_of(S.Sp, 2 * m + 1);
-            if (polished) {  // polishSz!: DN -> d, UP -> u  (SSQP.jl:12-16)
+            if (polished) {  // polishSz!: DN -> d, UP -> u  (SSQP.jl:12-16); the others keep their z
+                double2 zz;
+                zz.x = __hip_atomic_load(zg + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                zz.y = __hip_atomic_load(zg + r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const double2 dd = *reinterpret_cast<const double2 *>(C.dlo + r);
                 const double2 uu = *reinterpret_cast<const double2 *>(C.uhi + r);
                 zz.x = (s0 == SSQP_DN) ? dd.x : ((s0 == SSQP_UP) ? uu.x : zz.x);
                 zz.y = (s1 == SSQP_DN) ? dd.y : ((s1 == SSQP_UP) ? uu.y : zz.y);
+                *reinterpret_cast<double2 *>(zg + r) = zz;
             }
-            *reinterpret_cast<double2 *>(zg + r) = zz;
             Sg[r] = s0;
             Sg[r + 1] = s1;
         }
