@@ -122,6 +122,10 @@ def run(args):
     # With more than one rank the gather consumes the results stream-ordered, so everything stays queued.
     lazy = 1 if (world == 1 and args.streams > 1) else 0
     ctx.set_option("lazy_handover", lazy)
+    # wavefronts per CU of the wavefront kernel: with several batches in flight two per SIMD (8 per CU) give more QPs/s;
+    # a single 1024-QP launch fills 4 per CU exactly and runs fastest with one per SIMD (include/ssqp_hip.h)
+    qpc_lanes = 8 if args.streams > 1 else 4
+    ctx.set_option("wave_qp_per_cu", qpc_lanes)
     # V (the N*N*T part) is generated on the GPU, bit-identical to the host generator; the small arrays and the
     # Phase-1 vertex (x0, S0) come from the host C++ (not timed: the metric is the hot path solveQP(Q,S,x0))
     batch, prob, x0, S0 = pkg.DeviceBatch.generated(cfg, args.nprob, pkg.BASE_SEED + rank * args.nprob, ctx=ctx,
@@ -139,6 +143,7 @@ def run(args):
     for _ in range(1, nlanes):
         c2 = pkg.Context(local)
         c2.set_option("lazy_handover", lazy)
+        c2.set_option("wave_qp_per_cu", qpc_lanes)
         if args.dense:
             c2.set_option("dense_gamma", 1)
         lanes.append((batch.twin(c2), torch.cuda.Stream(dev)))
@@ -202,6 +207,7 @@ def run(args):
         return ms
     # (single launches on one stream: the kernels' own duration.  With several lanes the launches of the timed
     #  region overlap, and a launch's begin-to-end time then contains slot-sharing with its neighbours.)
+    ctx.set_option("wave_qp_per_cu", 4)   # (single launches from here on: one wavefront per SIMD)
     iso = timed_launches(4)
     k_ms = float(np.mean(iso))
     # the same K steps on ONE stream, for comparison with the pipelined figure
@@ -302,7 +308,8 @@ def run(args):
             "config": {"workload": "%s: %d QPs/GPU, N=%d M=%d J=%d, V=X'X/T+%g*I, box [0,%g], Phase-1 vertex "
                                    "resident in HBM" % (args.config, P, N, batch.M, J, cfg.delta, cfg.ub),
                        "qps_per_gpu": P,
-                       "parallelism": "one QP per wavefront (4 per CU), batch sharded over %d GPU(s)" % world,
+                       "parallelism": "one QP per wavefront (%d per CU in the timed region), batch sharded over %d GPU(s)"
+                                      % (qpc_lanes, world),
                        "formulation": "dense (reference-shaped)" if args.dense else "default (kept factor, cached products)"},
             "iters_to_kkt": {"mean": float(iters.mean()), "max": int(iters.max()), "min": int(iters.min())},
             "all_converged": ok,
@@ -311,6 +318,7 @@ def run(args):
                          "kernel_ms_last_timed_launch": last_kernel_ms,
                          "single_stream_ms_per_step": None if single is None else 1e3 * single,
                          "single_stream_qps": None if single is None else P / single,
+                         "wave_qp_per_cu": qpc_lanes,
                          "note": "steps are independent batches issued round-robin on `streams` HIP streams (one "
                                  "context per lane, shared inputs, per-lane outputs): the drain of one launch overlaps "
                                  "the ramp-up of the next; every step solves all its QPs from (x0, S0)"},

@@ -32,7 +32,7 @@ struct ssqp_ctx {
     int optDenseGamma = 0;   // 1: dense (reference-shaped) formulation -- roofline measurements
     int optIncremental = 1;  // 0: refactor V[F,F] from scratch in every pass
     int optWaveKernel = 1;   // 0: never use the wavefront-per-QP kernel
-    int optWaveQPC = 4;      // QPs (wavefronts) per CU of the wavefront kernel: 4..8
+    int optWaveQPC = 0;      // QPs (wavefronts) per CU of the wavefront kernel: 0 = by batch size, 1..4, 8
     int optLazyHandover = 0; // 1: the hand-over launch is deferred to ssqp_sync / the next call and skipped when empty
     int optPinHost = 0;      // 1: page-lock the caller's V array (kept registered until another array comes)
     const void *pinnedPtr = nullptr;
@@ -175,7 +175,7 @@ int ssqp_ctx_set_option(ssqp_ctx *c, const char *name, int value) {
         return SSQP_ERR_ARG;
     }
     if ((slot == &c->optWgPerCU && (value < 0 || value > ssqp::MAX_WG_PER_CU)) ||
-        (slot == &c->optWaveQPC && (value < 1 || value > 8)) ||
+        (slot == &c->optWaveQPC && (value < 0 || value > 8)) ||
         ((slot == &c->optDenseGamma || slot == &c->optIncremental || slot == &c->optWaveKernel || slot == &c->optPinHost ||
           slot == &c->optLazyHandover) &&
          (value != 0 && value != 1))) {
@@ -284,15 +284,25 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
     // the wavefront-per-QP kernel takes the shapes it is built for (N even <= 512, M + J <= 11) in the default
     // formulation; QPs it hands over (free set beyond its factor capacity) continue in the workgroup kernel
     const bool useWave = c->optWaveKernel && c->optIncremental && !c->optDenseGamma && ssqp::wave_kernel_applies(N, M, J);
-    int waveGrid = 0, waveRC = 0, waveLds = 0;
+    int waveGrid = 0, waveRC = 0, waveLds = 0, waveWps = 1;
     size_t wstride = 0;
     if (useWave) {
-        const int qpc = c->optWaveQPC;
-        const int perWave = (ssqp::LDS_BYTES / qpc) / 256 * 256;
-        waveRC = 127;
-        while (waveRC > 8 && ssqp::wave_lds_bytes(waveRC) > perWave) --waveRC;
-        if (waveRC > N) waveRC = N;
-        waveLds = ssqp::wave_lds_bytes(waveRC);
+        // 4 per CU (one wavefront per SIMD, 512 registers, everything in LDS) is the faster kernel per QP; 8 per CU (two per
+        // SIMD, 256 registers, rows >= 64 of the factor in global scratch) hides each wavefront's waits behind another
+        // one: the better choice when more QPs are in flight than 4 per CU -- a batch above 4 * numCU QPs, or several
+        // contexts busy on different streams (the caller says so with the option)
+        const int qpc = c->optWaveQPC > 0 ? c->optWaveQPC : (nprob > 4 * c->numCU ? 8 : 4);
+        if (qpc > 4) {  // two wavefronts per SIMD: 256 registers, rows >= 64 of the factor in global scratch
+            waveWps = 2;
+            waveRC = N < 127 ? N : 127;
+            waveLds = ssqp::wave_lds_bytes(0);
+        } else {
+            const int perWave = (ssqp::LDS_BYTES / qpc) / 256 * 256;
+            waveRC = 127;
+            while (waveRC > 8 && ssqp::wave_lds_bytes(waveRC) > perWave) --waveRC;
+            if (waveRC > N) waveRC = N;
+            waveLds = ssqp::wave_lds_bytes(waveRC);
+        }
         waveGrid = c->numCU * qpc;
         if (waveGrid > nprob) waveGrid = nprob;
         wstride = ssqp::wave_scratch_doubles(N, M, J);
@@ -348,7 +358,7 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
     if (!hip_ok(c, hipEventRecord(c->ev0, s), "hipEventRecord")) return SSQP_ERR_HIP;
     if (useWave) {
         P.queue = (unsigned int *)c->queue.p;
-        if (!hip_ok(c, ssqp::launch_solve_wave(P, waveGrid, s), "wave solve launch")) return SSQP_ERR_HIP;
+        if (!hip_ok(c, ssqp::launch_solve_wave(P, waveGrid, waveWps, s), "wave solve launch")) return SSQP_ERR_HIP;
         P.queue = (unsigned int *)c->queue.p + 1;
         P.resume = 1;  // (a grid that finds the hand-over list empty exits at once)
         if (c->optLazyHandover) {

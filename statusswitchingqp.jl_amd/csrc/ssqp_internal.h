@@ -140,11 +140,11 @@ hipError_t launch_solve(const SolveParams &P, int grid, size_t ldsBytes, int wgP
 constexpr int WAVE_MAXN = 512;   // dense N-vectors live in registers: 8 doubles per lane
 constexpr int WAVE_MJ = 11;      // constraint rows carried per free variable (M + J <= 11)
 bool wave_kernel_applies(int N, int M, int J);
-// LDS bytes one wavefront needs for a kept factor of `rc` rows (rc <= 127)
+// LDS bytes one wavefront needs for a kept factor of `rc` rows in LDS (rc <= 0: rows >= 64 in global scratch)
 int wave_lds_bytes(int rc);
 // doubles of global scratch per wavefront
 size_t wave_scratch_doubles(int N, int M, int J);
-hipError_t launch_solve_wave(const SolveParams &P, int grid, hipStream_t stream);
+hipError_t launch_solve_wave(const SolveParams &P, int grid, int wps, hipStream_t stream);
 
 // ---- Phase-1 on the GPU (ssqp_phase1.hip): one workgroup per QP
 size_t phase1_ws_doubles(int N, int M, int J);

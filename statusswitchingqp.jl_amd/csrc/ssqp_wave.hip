@@ -55,6 +55,7 @@ constexpr int NR = MJX + 1;   // border columns: every row of [A;G] and c
 constexpr int CC = MJX;       // index of the c column
 constexpr int NCH = 4;        // dense layout: element i sits in lane (i >> 1) & 63, chunk i >> 7, half i & 1
 constexpr int KSLOT = 64;     // rows per register slot
+constexpr int WAVE_LS_DOUBLES = 128 * MJX + MJX * MJX + MJX + 21;  // global scratch of the purged-row least squares
 constexpr double INF = __builtin_huge_val();
 
 // compile-time loop: the body sees its index as a constant, so every register-array index is static whatever
@@ -293,9 +294,7 @@ struct WLds {
     //  when it is appended or deleted -- and the rare paths (rank filter run in full, purged-row least squares,
     //  polishSz!) gather them from Ct)
     double *H;      // NR x NR, symmetric, full: H[a][b] = sum_r Y[a]_r Y[b]_r / d_r
-    double *Hs;     // W x W gathered block for the lambda solve
     double *tr;     // scratch of small_spd_solve
-    double *tv;     // right-hand side of the lambda solve
     double *aLrow;  // alphaL by row id
     double *yn;     // 16 doubles: a new border row / the downdate vector
     double *GG;     // MJX x MJX, symmetric, full: Gram matrix of the rows of [A;G][:, F]: GG[a][b] = sum_r X[a]_r X[b]_r
@@ -1997,8 +1996,13 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     wave_sync();
 }
 
-__global__ __launch_bounds__(64, 1) void ssqp_wave_kernel(SolveParams P) {
+// WPS = wavefronts per SIMD the register allocation allows.  WPS 1: four QPs per CU, 512 registers, the whole factor
+// (up to 92 rows) in LDS.  WPS 2: eight QPs per CU -- 256 registers, 20 KiB of LDS per QP: rows >= 64 of the factor
+// (under one per cent of the passes of the headline workload reach them) live in the wavefront's global scratch.
+template <int WPS>
+__global__ __launch_bounds__(64, WPS) void ssqp_wave_kernel(SolveParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool L1G = (WPS == 2);
     WLds L;
     {
         double *d0 = reinterpret_cast<double *>(smem);
@@ -2006,12 +2010,15 @@ __global__ __launch_bounds__(64, 1) void ssqp_wave_kernel(SolveParams P) {
         const int r1 = rc > 64 ? rc - 64 : 0;
         int o = 0;
         L.F.L0 = d0 + o; o += 2080;
-        L.F.L1 = d0 + o; o += rc * r1 + 2;
-        L.F.R1 = r1 > 0 ? r1 : 1;
+        if (L1G) {
+            L.F.L1 = P.wscratch + (size_t)blockIdx.x * P.wscratchStride + WAVE_LS_DOUBLES;
+            L.F.R1 = 64;
+        } else {
+            L.F.L1 = d0 + o; o += rc * r1 + 2;
+            L.F.R1 = r1 > 0 ? r1 : 1;
+        }
         L.H = d0 + o; o += NR * NR;
-        L.Hs = d0 + o; o += MJX * MJX + 1;
         L.tr = d0 + o; o += MJX * MJX + 1;
-        L.tv = d0 + o; o += 16;
         L.aLrow = d0 + o; o += 16;
         L.yn = d0 + o; o += 16;
         L.GG = d0 + o; o += MJX * MJX + 1;
@@ -2031,21 +2038,24 @@ __global__ __launch_bounds__(64, 1) void ssqp_wave_kernel(SolveParams P) {
 bool wave_kernel_applies(int N, int M, int J) {
     return (N % 2 == 0) && N >= 2 && N <= WAVE_MAXN && (M + J) <= WAVE_MJ;
 }
-int wave_lds_bytes(int rc) {
+int wave_lds_bytes(int rc) {  // rc <= 0: the eight-per-CU variant (rows >= 64 in global scratch)
     const int r1 = rc > 64 ? rc - 64 : 0;
-    const int dbl = 2080 + rc * r1 + 2 + NR * NR + 3 * (MJX * MJX + 1) + 16 * 4 + 8;
+    const int l1 = rc > 0 ? rc * r1 + 2 : 0;
+    const int dbl = 2080 + l1 + NR * NR + 2 * (MJX * MJX + 1) + 16 * 3 + 8;
     return dbl * 8;
 }
 size_t wave_scratch_doubles(int N, int M, int J) {
-    (void)N;
-    const size_t W = (size_t)(M + J);
-    return 128 * W + W * W + W + 64;
+    (void)N; (void)M; (void)J;
+    // least-squares scratch, then (eight-per-CU variant) rows 64..127 of up to 128 columns of the factor
+    return (size_t)WAVE_LS_DOUBLES + 128 * 64 + 64;
 }
-hipError_t launch_solve_wave(const SolveParams &P, int grid, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ssqp_wave_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, P.waveLdsBytes);
+hipError_t launch_solve_wave(const SolveParams &P, int grid, int wps, hipStream_t stream) {
+    const void *fn = (wps == 2) ? reinterpret_cast<const void *>(&ssqp_wave_kernel<2>)
+                                : reinterpret_cast<const void *>(&ssqp_wave_kernel<1>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P.waveLdsBytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ssqp_wave_kernel, dim3(grid), dim3(64), (size_t)P.waveLdsBytes, stream, P);
+    if (wps == 2) hipLaunchKernelGGL(ssqp_wave_kernel<2>, dim3(grid), dim3(64), (size_t)P.waveLdsBytes, stream, P);
+    else hipLaunchKernelGGL(ssqp_wave_kernel<1>, dim3(grid), dim3(64), (size_t)P.waveLdsBytes, stream, P);
     return hipGetLastError();
 }
 

@@ -29,6 +29,7 @@ def run_cfg(pkg, orc, cfg, nprob, seed0=None, rtol=1e-10, opts=None, both=True):
     runs = [dict(opts or {})]
     if opts is None and both and cfg.N % 2 == 0 and cfg.N <= 512 and cfg.M + cfg.J <= 11:
         runs.append(dict(wave_kernel=0))
+        runs.append(dict(wave_qp_per_cu=8))     # the two-wavefronts-per-SIMD build of the wavefront kernel
     first = None
     for o in runs:
         with ctx.options(**o):
@@ -270,6 +271,10 @@ def _check_shapes(pkg, orc, kind, rng, shapes, nper, need):
             continue
         sub = {k: np.ascontiguousarray(v[ok]) for k, v in prob.items()}
         z, S, status, detail = pkg.solveQP_batch(sub, S0[ok], x0[ok])
+        if N % 2 == 0 and N <= 512 and M + J <= 11:      # ... and the same through the eight-per-CU wavefront kernel
+            with pkg.default_context().options(wave_qp_per_cu=8):
+                z8, S8, status8, _ = pkg.solveQP_batch(sub, S0[ok], x0[ok])
+            assert np.array_equal(status8, status) and np.array_equal(S8, S) and np.array_equal(z8, z), (kind, N, M, J)
         zo, So, sto, deto, _ = oracle_batch(orc, sub, S0[ok], x0[ok])
         conv = sto > 0
         assert np.array_equal(status, sto), (kind, N, M, J, status, sto)
