@@ -274,7 +274,10 @@ def _check_shapes(pkg, orc, kind, rng, shapes, nper, need):
         if N % 2 == 0 and N <= 512 and M + J <= 11:      # ... and the same through the eight-per-CU wavefront kernel
             with pkg.default_context().options(wave_qp_per_cu=8):
                 z8, S8, status8, _ = pkg.solveQP_batch(sub, S0[ok], x0[ok])
-            assert np.array_equal(status8, status) and np.array_equal(S8, S) and np.array_equal(z8, z), (kind, N, M, J)
+            # (same source, two register budgets: the compiler may contract a*b+c differently, so z agrees to rounding)
+            assert np.array_equal(status8, status) and np.array_equal(S8, S), (kind, N, M, J)
+            fin8 = np.isfinite(z).all(axis=1)
+            assert np.abs(z8[fin8] - z[fin8]).max() <= 1e-12 * max(1.0, np.abs(z[fin8]).max()) if fin8.any() else True
         zo, So, sto, deto, _ = oracle_batch(orc, sub, S0[ok], x0[ok])
         conv = sto > 0
         assert np.array_equal(status, sto), (kind, N, M, J, status, sto)
