@@ -144,7 +144,8 @@ bool wave_kernel_applies(int N, int M, int J);
 int wave_lds_bytes(int rc);
 // doubles of global scratch per wavefront
 size_t wave_scratch_doubles(int N, int M, int J);
-hipError_t launch_solve_wave(const SolveParams &P, int grid, int wps, hipStream_t stream);
+// variant 0: four QPs per CU (one wavefront per SIMD, every row in LDS); 1: eight per CU (rows >= 64 in global scratch)
+hipError_t launch_solve_wave(const SolveParams &P, int grid, int variant, hipStream_t stream);
 
 // ---- Phase-1 on the GPU (ssqp_phase1.hip): one workgroup per QP
 size_t phase1_ws_doubles(int N, int M, int J);

@@ -34,7 +34,7 @@ namespace ssqp {
 #ifdef SSQP_PHASE_PROFILE
 // (accumulated in registers and flushed once per QP: an atomic per stamp would sit in front of every later load of
 // the phase -- vector memory operations complete in order -- and charge its own round trip to that phase)
-__device__ unsigned long long g_wphase[64];
+static __device__ unsigned long long g_wphase[64];  // (one per build of the kernel)
 #define WPH_DECL unsigned long long wph_t = __builtin_amdgcn_s_memtime()
 #define WPH(slot)                                                        \
     do {                                                                 \
@@ -55,7 +55,7 @@ constexpr int NR = MJX + 1;   // border columns: every row of [A;G] and c
 constexpr int CC = MJX;       // index of the c column
 constexpr int NCH = 4;        // dense layout: element i sits in lane (i >> 1) & 63, chunk i >> 7, half i & 1
 constexpr int KSLOT = 64;     // rows per register slot
-constexpr int WAVE_LS_DOUBLES = 128 * MJX + MJX * MJX + MJX + 21;  // global scratch of the purged-row least squares
+[[maybe_unused]] constexpr int WAVE_LS_DOUBLES = 128 * MJX + MJX * MJX + MJX + 21;  // global scratch of the purged-row least squares
 constexpr double INF = __builtin_huge_val();
 
 // compile-time loop: the body sees its index as a constant, so every register-array index is static whatever
@@ -1777,6 +1777,8 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
     return W_CONTINUE;
 }
 
+// ONE: the build with one row slot per lane -- a QP whose free set outgrows 63 variables is handed over.
+template <bool ONE>
 __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, const WLds &L, double *gscr) {
     const int lane = lane_id();
     const int N = P.N, M = P.M, J = P.J, MJ = P.MJ;
@@ -1792,7 +1794,8 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     C.trace = P.trace ? P.trace + (size_t)prob * P.ntrace : nullptr;
     C.ntrace = P.ntrace;
     C.RC = P.waveRC;
-    C.iter = 0; C.ret = 0; C.det = SSQP_DETAIL_NONE;
+    C.iter = 0;
+    C.ret = 0; C.det = SSQP_DETAIL_NONE;
     C.sBytes = 0; C.sRead = 0; C.sFlops = 0; C.sK3 = 0; C.maxK = 0;
 #ifdef SSQP_PHASE_PROFILE
 #pragma unroll
@@ -1819,7 +1822,8 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
 #pragma unroll
     for (int m = 0; m < NCH; ++m) {
         const int r = 2 * lane + 128 * m;
-        if (r < N) *reinterpret_cast<double2 *>(S.zg + r) = *reinterpret_cast<const double2 *>(P.x0 + (size_t)prob * N + r);
+        if (r < N)
+            *reinterpret_cast<double2 *>(S.zg + r) = *reinterpret_cast<const double2 *>(P.x0 + (size_t)prob * N + r);
         const int s0 = (r < N) ? Sg[r] : SSQP_DN, s1 = (r < N) ? Sg[r + 1] : SSQP_DN;
         S.Sp |= ((unsigned)s0 & 15u) << (8 * m);
         S.Sp |= ((unsigned)s1 & 15u) << (8 * m + 4);
@@ -1874,11 +1878,11 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
                 nin += __popcll(__ballot(2 * lane + 128 * (k >> 1) < N && st_of(S.Sp, k) == SSQP_IN));
             Knew = nin;
         }
-        if (Knew > C.RC) {
+        if (Knew > C.RC || (ONE && Knew > 63)) {
             handover = true;
             break;
         }
-        const bool two = (S.K > 63) || (Knew > 63);
+        const bool two = !ONE && ((S.K > 63) || (Knew > 63));
         int act;
         if (two) act = wave_sync_factor<2>(C, L, S);
         else act = wave_sync_factor<1>(C, L, S);
@@ -1996,13 +2000,16 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     wave_sync();
 }
 
-// WPS = wavefronts per SIMD the register allocation allows.  WPS 1: four QPs per CU, 512 registers, the whole factor
-// (up to 92 rows) in LDS.  WPS 2: eight QPs per CU -- 256 registers, 20 KiB of LDS per QP: rows >= 64 of the factor
-// (under one per cent of the passes of the headline workload reach them) live in the wavefront's global scratch.
-template <int WPS>
+// Two builds of the kernel, one per translation unit (SSQP_WAVE_VARIANT) so that they compile side by side:
+//   0: <1, false>  one wavefront per SIMD -- four QPs per CU, 512 registers, up to ~90 free variables, the whole
+//                  factor in LDS;
+//   1: <2, true>   two per SIMD -- eight QPs per CU, 256 registers, one row slot per lane: at most 63 free variables.
+// Either hands a QP that outgrows it over to the workgroup kernel.  Under one per cent of the passes of the headline
+// workload have more than 63 free variables, and carrying the second row slot through every pass would cost the
+// 256-register build some 130 spilled registers (measured: a tenth of its throughput).
+template <int WPS, bool ONE>
 __global__ __launch_bounds__(64, WPS) void ssqp_wave_kernel(SolveParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr bool L1G = (WPS == 2);
     WLds L;
     {
         double *d0 = reinterpret_cast<double *>(smem);
@@ -2010,9 +2017,9 @@ __global__ __launch_bounds__(64, WPS) void ssqp_wave_kernel(SolveParams P) {
         const int r1 = rc > 64 ? rc - 64 : 0;
         int o = 0;
         L.F.L0 = d0 + o; o += 2080;
-        if (L1G) {
-            L.F.L1 = P.wscratch + (size_t)blockIdx.x * P.wscratchStride + WAVE_LS_DOUBLES;
-            L.F.R1 = 64;
+        if (ONE) {  // (no rows >= 64)
+            L.F.L1 = d0;
+            L.F.R1 = 1;
         } else {
             L.F.L1 = d0 + o; o += rc * r1 + 2;
             L.F.R1 = r1 > 0 ? r1 : 1;
@@ -2031,14 +2038,51 @@ __global__ __launch_bounds__(64, WPS) void ssqp_wave_kernel(SolveParams P) {
         if (threadIdx.x == 0) prob = (int)atomicAdd(P.queue, 1u);
         prob = __builtin_amdgcn_readfirstlane(prob);
         if (prob >= P.nprob) break;
-        wave_solve_one(P, prob, L, gscr);
+        wave_solve_one<ONE>(P, prob, L, gscr);
     }
 }
 
+#ifndef SSQP_WAVE_VARIANT
+#define SSQP_WAVE_VARIANT 0
+#endif
+#if SSQP_WAVE_VARIANT == 0
+#define WV_KERNEL ssqp_wave_kernel<1, false>
+#define WV_LAUNCH launch_wave_v0
+#define WV_PHASES wave_phases_v0
+#elif SSQP_WAVE_VARIANT == 1
+#define WV_KERNEL ssqp_wave_kernel<2, true>
+#define WV_LAUNCH launch_wave_v1
+#define WV_PHASES wave_phases_v1
+#else
+#error "SSQP_WAVE_VARIANT: 0 or 1"
+#endif
+
+hipError_t WV_LAUNCH(const SolveParams &P, int grid, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&WV_KERNEL),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, P.waveLdsBytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(WV_KERNEL, dim3(grid), dim3(64), (size_t)P.waveLdsBytes, stream, P);
+    return hipGetLastError();
+}
+#ifdef SSQP_PHASE_PROFILE
+int WV_PHASES(unsigned long long *out64, int reset) {  // adds this build's stamps to out64
+    unsigned long long h[64];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wphase), sizeof(h)) != hipSuccess) return 1;
+    for (int k = 0; k < 64; ++k) out64[k] += h[k];
+    if (reset) {
+        static unsigned long long zero[64];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_wphase), zero, sizeof(zero)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
+
+#if SSQP_WAVE_VARIANT == 0
+hipError_t launch_wave_v1(const SolveParams &P, int grid, hipStream_t stream);
 bool wave_kernel_applies(int N, int M, int J) {
     return (N % 2 == 0) && N >= 2 && N <= WAVE_MAXN && (M + J) <= WAVE_MJ;
 }
-int wave_lds_bytes(int rc) {  // rc <= 0: the eight-per-CU variant (rows >= 64 in global scratch)
+int wave_lds_bytes(int rc) {  // rc <= 0: the one-slot build (no rows >= 64)
     const int r1 = rc > 64 ? rc - 64 : 0;
     const int l1 = rc > 0 ? rc * r1 + 2 : 0;
     const int dbl = 2080 + l1 + NR * NR + 2 * (MJX * MJX + 1) + 16 * 3 + 8;
@@ -2046,28 +2090,22 @@ int wave_lds_bytes(int rc) {  // rc <= 0: the eight-per-CU variant (rows >= 64 i
 }
 size_t wave_scratch_doubles(int N, int M, int J) {
     (void)N; (void)M; (void)J;
-    // least-squares scratch, then (eight-per-CU variant) rows 64..127 of up to 128 columns of the factor
-    return (size_t)WAVE_LS_DOUBLES + 128 * 64 + 64;
+    return (size_t)WAVE_LS_DOUBLES + 64;  // least-squares scratch of the purged-row multipliers
 }
-hipError_t launch_solve_wave(const SolveParams &P, int grid, int wps, hipStream_t stream) {
-    const void *fn = (wps == 2) ? reinterpret_cast<const void *>(&ssqp_wave_kernel<2>)
-                                : reinterpret_cast<const void *>(&ssqp_wave_kernel<1>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P.waveLdsBytes);
-    if (e != hipSuccess) return e;
-    if (wps == 2) hipLaunchKernelGGL(ssqp_wave_kernel<2>, dim3(grid), dim3(64), (size_t)P.waveLdsBytes, stream, P);
-    else hipLaunchKernelGGL(ssqp_wave_kernel<1>, dim3(grid), dim3(64), (size_t)P.waveLdsBytes, stream, P);
-    return hipGetLastError();
+hipError_t launch_solve_wave(const SolveParams &P, int grid, int variant, hipStream_t stream) {
+    if (variant == 1) return launch_wave_v1(P, grid, stream);
+    return launch_wave_v0(P, grid, stream);
 }
+#endif  // SSQP_WAVE_VARIANT == 0
 
 }  // namespace ssqp
 
-#ifdef SSQP_PHASE_PROFILE
+#if defined(SSQP_PHASE_PROFILE) && SSQP_WAVE_VARIANT == 0
+namespace ssqp {
+int wave_phases_v1(unsigned long long *out64, int reset);
+}
 extern "C" int ssqp_debug_wave_phases(unsigned long long *out64, int reset) {
-    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(ssqp::g_wphase), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
-    if (reset) {
-        static unsigned long long zero[64];
-        if (hipMemcpyToSymbol(HIP_SYMBOL(ssqp::g_wphase), zero, sizeof(zero)) != hipSuccess) return 1;
-    }
-    return 0;
+    for (int k = 0; k < 64; ++k) out64[k] = 0;
+    return ssqp::wave_phases_v0(out64, reset) | ssqp::wave_phases_v1(out64, reset);
 }
 #endif

@@ -2,10 +2,16 @@
 # Register / spill / scratch figures of every solve kernel as the compiler reports them in the code-object metadata
 # (same flags as the Makefile; --cuda-device-only -S keeps the AMDGPU assembly with its .amdhsa metadata).
 cd "$(dirname "$0")/../statusswitchingqp.jl_amd/csrc"
-for f in ssqp_wave.hip ssqp_kernels.hip ssqp_phase1.hip; do
+for spec in ssqp_wave.hip:0 ssqp_wave.hip:1 ssqp_kernels.hip: ssqp_phase1.hip:; do
+  f=${spec%%:*}; v=${spec##*:}
   extra=""; [ $f = ssqp_phase1.hip ] && extra="-ffp-contract=off"
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -I../../include -I. -mllvm -sink-insts-to-avoid-spills=1 $extra -S --cuda-device-only $f -o /tmp/notes_$f.s 2>/dev/null
-  python3 - /tmp/notes_$f.s $f <<'PY'
+  [ -n "$v" ] && extra="-DSSQP_WAVE_VARIANT=$v"
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -I../../include -I. -mllvm -sink-insts-to-avoid-spills=1 $extra -S --cuda-device-only $f -o /tmp/notes_$f$v.s 2>/dev/null &
+done
+wait
+for spec in ssqp_wave.hip:0 ssqp_wave.hip:1 ssqp_kernels.hip: ssqp_phase1.hip:; do
+  f=${spec%%:*}; v=${spec##*:}
+  python3 - /tmp/notes_$f$v.s $f <<'PY'
 import re,sys
 txt=open(sys.argv[1]).read()
 md=txt[txt.index('amdhsa.kernels:'):]
