@@ -108,8 +108,8 @@ const char *ssqp_last_error(const ssqp_ctx *ctx);
  *                     -- the lowest latency per QP; 8 = two per SIMD, 256 registers, at most 63 free variables (QPs that
  *                     need more are handed over) -- more QPs per second when more than 4 per CU are in flight (large
  *                     batches, several contexts on different streams); 0 (default) = 8 for batches above 4 * numCU QPs,
- *                     else 4, and 4 again for a shape whose previous batch had the 8-per-CU build hand over more than
- *                     an eighth of its QPs
+ *                     else 4, and 4 again for a shape whose previous batch left more than about a seventh of its
+ *                     passes to the workgroup kernel that way
  *   "incremental"     1 (default): keep the LDL' factor of V[F,F] across passes; 0: refactor in every pass like
  *                     SSQP.jl:322 (workgroup kernel)
  *   "dense_gamma"     1: the reference's dense formulation (from-scratch factor, gamma pass over all N columns,

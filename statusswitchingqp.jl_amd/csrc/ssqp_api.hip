@@ -43,8 +43,9 @@ struct ssqp_ctx {
     DevBuf hV, hA, hG, hq, hb, hg, hd, hu, hS, hx0, hz, hstatus, hdetail, hstats;
     // lazy hand-over: the launch the wavefront kernel may still owe (its hand-over count lands in pinned memory)
     unsigned int *hostCount = nullptr;   // pinned
-    // how the last wavefront launch fared (read from hostCount once its copy has landed): when the one-slot build hands
-    // over more than an eighth of a batch, the by-batch-size choice falls back to the all-rows build for that shape
+    // how the last wavefront launch fared (read from hostCount once its copy has landed): when the one-slot build leaves
+    // a sizeable part of the passes to the workgroup kernel, the by-batch-size choice falls back to the all-rows build
+    // for that shape (note_handover)
     bool countOwed = false;
     int lastShape[3] = {0, 0, 0}, lastNprob = 0, lastQpc = 0;
     int avoidShape[3] = {0, 0, 0}, avoidLeft = 0;
@@ -199,11 +200,24 @@ int ssqp_ctx_get_option(ssqp_ctx *c, const char *name, int *value) {
 
 // lazy hand-over: wait for the wavefront kernel of the last call, and launch the workgroup kernel on its hand-over
 // list only when that list is not empty (on the stream of that call, so later work on it stays ordered)
-// the hand-over count of the last wavefront launch has landed in hostCount
+// The counters of the last wavefront launch have landed in hostCount: [0] QPs handed over, [3] passes they had done by
+// then, [4] passes of the QPs the kernel finished itself, [5] their number.  The eight-per-CU build is the wrong choice
+// for a shape when a sizeable part of all passes is left to the workgroup kernel: estimated as (handed over) x (mean
+// length of the finished ones) - (passes done before the hand-over); cfg4 hands half of its QPs over, but in their last
+// tenth (7 % of the passes) and is 9 % faster for it, a workload that ends with 70-80 free variables loses everything.
 static void note_handover(ssqp_ctx *c) {
     if (!c->countOwed) return;
     c->countOwed = false;
-    if (c->lastQpc > 4 && (long long)*c->hostCount * 8 > (long long)c->lastNprob) {
+    if (c->lastQpc <= 4) return;
+    const double nA = c->hostCount[0], A = c->hostCount[3], B = c->hostCount[4], nB = c->hostCount[5];
+    if (nA <= 0) return;
+    bool poor = nB <= 0;
+    if (!poor) {
+        double left = nA * (B / nB) - A;
+        if (left < 0) left = 0;
+        poor = left > 0.15 * (A + B + left);
+    }
+    if (poor) {
         for (int k = 0; k < 3; ++k) c->avoidShape[k] = c->lastShape[k];
         c->avoidLeft = 64;  // batches of this shape before the one-slot build gets another try
     }
@@ -358,7 +372,8 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
     P.gscratchStride = gstride;
     P.denseGamma = c->optDenseGamma;
     P.incremental = c->optDenseGamma ? 0 : c->optIncremental;  // the dense run is the from-scratch, reference-shaped pass
-    // queue words: [0] work counter of the wavefront kernel, [1] of the workgroup kernel, [2] hand-over count
+    // queue words: [0] work counter of the wavefront kernel, [1] of the workgroup kernel, [2] hand-over count,
+    // [5..7] pass counts of the wavefront kernel for note_handover
     P.fbCount = (unsigned int *)c->queue.p + 2;
     P.fbList = (int *)c->fbList.p;
     P.fbIter = (long long *)c->fbIter.p;
@@ -391,7 +406,7 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
             return SSQP_ERR_HIP;
         if (!c->optLazyHandover && !c->countOwed) {
             // (eager mode: the count still comes to the host, for the choice of the build at the next call)
-            if (!hip_ok(c, hipMemcpyAsync(c->hostCount, P.fbCount, 4, hipMemcpyDeviceToHost, s), "D2H") ||
+            if (!hip_ok(c, hipMemcpyAsync(c->hostCount, P.fbCount, 24, hipMemcpyDeviceToHost, s), "D2H") ||
                 !hip_ok(c, hipEventRecord(c->evCount, s), "hipEventRecord"))
                 return SSQP_ERR_HIP;
             c->countOwed = true;
@@ -404,7 +419,7 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
             // context it would wait for that even when there is nothing to do.  Lazy mode: the hand-over count comes to
             // pinned host memory and the launch is issued by ssqp_sync / the next call only if the count is not zero.
             if (!hip_ok(c, hipEventRecord(c->ev1, s), "hipEventRecord")) return SSQP_ERR_HIP;
-            if (!hip_ok(c, hipMemcpyAsync(c->hostCount, P.fbCount, 4, hipMemcpyDeviceToHost, s), "D2H") ||
+            if (!hip_ok(c, hipMemcpyAsync(c->hostCount, P.fbCount, 24, hipMemcpyDeviceToHost, s), "D2H") ||
                 !hip_ok(c, hipEventRecord(c->evCount, s), "hipEventRecord"))
                 return SSQP_ERR_HIP;
             c->countOwed = true;

@@ -1992,9 +1992,12 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
             P.fbIter[prob] = C.iter - 1;  // passes completed
             const unsigned slot = atomicAdd(P.fbCount, 1u);
             P.fbList[slot] = prob;
-        } else {
+            (void)atomicAdd(P.queue + 5, (unsigned)(C.iter - 1));  // (for the host's choice of the build: how late
+        } else {                                                   //  hand-overs come, see ssqp_api.hip)
             P.status[prob] = C.ret;
             if (P.detail) P.detail[prob] = C.det;
+            (void)atomicAdd(P.queue + 6, (unsigned)(C.iter > P.maxIter ? P.maxIter : C.iter));
+            (void)atomicAdd(P.queue + 7, 1u);
         }
     }
     wave_sync();
