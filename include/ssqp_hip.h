@@ -104,12 +104,11 @@ const char *ssqp_last_error(const ssqp_ctx *ctx);
  *   "wave_kernel"     1 (default): QPs of a shape the wavefront-per-QP kernel takes (N even <= 512, M+J <= 11)
  *                     run there and are handed over to the workgroup kernel only when their free set outgrows
  *                     it; 0: workgroup kernel only
- *   "wave_qp_per_cu"  QPs (wavefronts) per CU of that kernel: 4 = one per SIMD, 512 registers, up to 92 free variables
- *                     -- the lowest latency per QP; 8 = two per SIMD, 256 registers, at most 63 free variables (QPs that
- *                     need more are handed over) -- more QPs per second when more than 4 per CU are in flight (large
- *                     batches, several contexts on different streams); 0 (default) = 8 for batches above 4 * numCU QPs,
- *                     else 4, and 4 again for a shape whose previous batch left more than about a seventh of its
- *                     passes to the workgroup kernel that way
+ *   "wave_qp_per_cu"  QPs (wavefronts) per CU of that kernel: 4 = one per SIMD, 512 registers, the factor (up to 92 rows)
+ *                     in LDS -- the lowest latency per QP; 8 = two per SIMD, 256 registers, rows >= 64 of the factor (and,
+ *                     between the passes that use it, the second row slot) in global scratch, up to 127 rows -- more
+ *                     QPs per second when more than 4 per CU are in flight (large batches,
+ *                     several contexts on different streams); 0 (default) = 8 for batches above 4 * numCU QPs, else 4
  *   "incremental"     1 (default): keep the LDL' factor of V[F,F] across passes; 0: refactor in every pass like
  *                     SSQP.jl:322 (workgroup kernel)
  *   "dense_gamma"     1: the reference's dense formulation (from-scratch factor, gamma pass over all N columns,

@@ -43,12 +43,6 @@ struct ssqp_ctx {
     DevBuf hV, hA, hG, hq, hb, hg, hd, hu, hS, hx0, hz, hstatus, hdetail, hstats;
     // lazy hand-over: the launch the wavefront kernel may still owe (its hand-over count lands in pinned memory)
     unsigned int *hostCount = nullptr;   // pinned
-    // how the last wavefront launch fared (read from hostCount once its copy has landed): when the one-slot build leaves
-    // a sizeable part of the passes to the workgroup kernel, the by-batch-size choice falls back to the all-rows build
-    // for that shape (note_handover)
-    bool countOwed = false;
-    int lastShape[3] = {0, 0, 0}, lastNprob = 0, lastQpc = 0;
-    int avoidShape[3] = {0, 0, 0}, avoidLeft = 0;
     hipEvent_t evCount = nullptr;
     bool pending = false;
     ssqp::SolveParams pendP;
@@ -200,34 +194,10 @@ int ssqp_ctx_get_option(ssqp_ctx *c, const char *name, int *value) {
 
 // lazy hand-over: wait for the wavefront kernel of the last call, and launch the workgroup kernel on its hand-over
 // list only when that list is not empty (on the stream of that call, so later work on it stays ordered)
-// The counters of the last wavefront launch have landed in hostCount: [0] QPs handed over, [3] passes they had done by
-// then, [4] passes of the QPs the kernel finished itself, [5] their number.  The eight-per-CU build is the wrong choice
-// for a shape when a sizeable part of all passes is left to the workgroup kernel: estimated as (handed over) x (mean
-// length of the finished ones) - (passes done before the hand-over); cfg4 hands half of its QPs over, but in their last
-// tenth (7 % of the passes) and is 9 % faster for it, a workload that ends with 70-80 free variables loses everything.
-static void note_handover(ssqp_ctx *c) {
-    if (!c->countOwed) return;
-    c->countOwed = false;
-    if (c->lastQpc <= 4) return;
-    const double nA = c->hostCount[0], A = c->hostCount[3], B = c->hostCount[4], nB = c->hostCount[5];
-    if (nA <= 0) return;
-    bool poor = nB <= 0;
-    if (!poor) {
-        double left = nA * (B / nB) - A;
-        if (left < 0) left = 0;
-        poor = left > 0.15 * (A + B + left);
-    }
-    if (poor) {
-        for (int k = 0; k < 3; ++k) c->avoidShape[k] = c->lastShape[k];
-        c->avoidLeft = 64;  // batches of this shape before the one-slot build gets another try
-    }
-}
-
 static int finish_pending(ssqp_ctx *c) {
     if (!c->pending) return SSQP_OK;
     c->pending = false;
     if (!hip_ok(c, hipEventSynchronize(c->evCount), "hipEventSynchronize")) return SSQP_ERR_HIP;
-    note_handover(c);
     if (*c->hostCount == 0) return SSQP_OK;
     if (!hip_ok(c, ssqp::launch_solve(c->pendP, c->pendGrid, c->pendLds, c->pendWg, c->pendStream), "solve launch"))
         return SSQP_ERR_HIP;
@@ -314,25 +284,18 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
     // the wavefront-per-QP kernel takes the shapes it is built for (N even <= 512, M + J <= 11) in the default
     // formulation; QPs it hands over (free set beyond its factor capacity) continue in the workgroup kernel
     const bool useWave = c->optWaveKernel && c->optIncremental && !c->optDenseGamma && ssqp::wave_kernel_applies(N, M, J);
-    int waveGrid = 0, waveRC = 0, waveLds = 0, waveWps = 1, waveQpc = 0;
+    int waveGrid = 0, waveRC = 0, waveLds = 0, waveWps = 1;
     size_t wstride = 0;
     if (useWave) {
-        // 4 per CU (one wavefront per SIMD, 512 registers, up to ~90 free variables) is the faster kernel per QP; 8 per CU
-        // (two per SIMD, 256 registers, at most 63 free variables) hides each wavefront's waits behind another one: the
-        // better choice when more QPs are in flight than 4 per CU -- a batch above 4 * numCU QPs, or several contexts
-        // busy on different streams (the caller says so with the option) -- unless the free sets of this workload
-        // outgrow it: the count of the previous launch tells
-        if (c->countOwed && c->evCount && hipEventQuery(c->evCount) == hipSuccess) note_handover(c);
-        int qpc = c->optWaveQPC > 0 ? c->optWaveQPC : (nprob > 4 * c->numCU ? 8 : 4);
-        if (c->optWaveQPC == 0 && qpc > 4 && c->avoidLeft > 0 && c->avoidShape[0] == N && c->avoidShape[1] == M &&
-            c->avoidShape[2] == J) {
-            c->avoidLeft -= 1;
-            qpc = 4;
-        }
-        waveQpc = qpc;
-        if (qpc > 4) {  // two wavefronts per SIMD: 256 registers, one row slot per lane
+        // 4 per CU (one wavefront per SIMD, 512 registers, everything in LDS) is the faster kernel per QP; 8 per CU (two per
+        // SIMD, 256 registers, rows >= 64 of the factor and -- between the passes that use it -- the second row slot in
+        // global scratch) hides each wavefront's waits behind another one: the better choice when more QPs are in flight
+        // than 4 per CU -- a batch above 4 * numCU QPs, or several contexts busy on different streams (the caller says
+        // so with the option)
+        const int qpc = c->optWaveQPC > 0 ? c->optWaveQPC : (nprob > 4 * c->numCU ? 8 : 4);
+        if (qpc > 4) {  // two wavefronts per SIMD: 256 registers, rows >= 64 of the factor in global scratch
             waveWps = 2;
-            waveRC = N < 63 ? N : 63;
+            waveRC = N < 127 ? N : 127;
             waveLds = ssqp::wave_lds_bytes(0);
         } else {
             const int perWave = (ssqp::LDS_BYTES / qpc) / 256 * 256;
@@ -372,8 +335,7 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
     P.gscratchStride = gstride;
     P.denseGamma = c->optDenseGamma;
     P.incremental = c->optDenseGamma ? 0 : c->optIncremental;  // the dense run is the from-scratch, reference-shaped pass
-    // queue words: [0] work counter of the wavefront kernel, [1] of the workgroup kernel, [2] hand-over count,
-    // [5..7] pass counts of the wavefront kernel for note_handover
+    // queue words: [0] work counter of the wavefront kernel, [1] of the workgroup kernel, [2] hand-over count
     P.fbCount = (unsigned int *)c->queue.p + 2;
     P.fbList = (int *)c->fbList.p;
     P.fbIter = (long long *)c->fbIter.p;
@@ -400,32 +362,18 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
         if (!hip_ok(c, ssqp::launch_solve_wave(P, waveGrid, waveWps == 2 ? 1 : 0, s), "wave solve launch")) return SSQP_ERR_HIP;
         P.queue = (unsigned int *)c->queue.p + 1;
         P.resume = 1;  // (a grid that finds the hand-over list empty exits at once)
-        if (!c->hostCount && !hip_ok(c, hipHostMalloc((void **)&c->hostCount, 64, hipHostMallocDefault), "hipHostMalloc"))
-            return SSQP_ERR_ALLOC;
-        if (!c->evCount && !hip_ok(c, hipEventCreateWithFlags(&c->evCount, hipEventDisableTiming), "hipEventCreate"))
-            return SSQP_ERR_HIP;
-        if (!c->optLazyHandover && !c->countOwed) {
-            // (eager mode: the count still comes to the host, for the choice of the build at the next call)
-            if (!hip_ok(c, hipMemcpyAsync(c->hostCount, P.fbCount, 24, hipMemcpyDeviceToHost, s), "D2H") ||
-                !hip_ok(c, hipEventRecord(c->evCount, s), "hipEventRecord"))
-                return SSQP_ERR_HIP;
-            c->countOwed = true;
-            c->lastShape[0] = N; c->lastShape[1] = M; c->lastShape[2] = J;
-            c->lastNprob = nprob;
-            c->lastQpc = waveQpc;
-        }
         if (c->optLazyHandover) {
             // The workgroup kernel needs a CU with 80 KiB of LDS and four free register files: behind a launch of another
             // context it would wait for that even when there is nothing to do.  Lazy mode: the hand-over count comes to
             // pinned host memory and the launch is issued by ssqp_sync / the next call only if the count is not zero.
+            if (!c->hostCount && !hip_ok(c, hipHostMalloc((void **)&c->hostCount, 64, hipHostMallocDefault), "hipHostMalloc"))
+                return SSQP_ERR_ALLOC;
+            if (!c->evCount && !hip_ok(c, hipEventCreateWithFlags(&c->evCount, hipEventDisableTiming), "hipEventCreate"))
+                return SSQP_ERR_HIP;
             if (!hip_ok(c, hipEventRecord(c->ev1, s), "hipEventRecord")) return SSQP_ERR_HIP;
-            if (!hip_ok(c, hipMemcpyAsync(c->hostCount, P.fbCount, 24, hipMemcpyDeviceToHost, s), "D2H") ||
+            if (!hip_ok(c, hipMemcpyAsync(c->hostCount, P.fbCount, 4, hipMemcpyDeviceToHost, s), "D2H") ||
                 !hip_ok(c, hipEventRecord(c->evCount, s), "hipEventRecord"))
                 return SSQP_ERR_HIP;
-            c->countOwed = true;
-            c->lastShape[0] = N; c->lastShape[1] = M; c->lastShape[2] = J;
-            c->lastNprob = nprob;
-            c->lastQpc = waveQpc;
             c->pendP = P;
             c->pendGrid = grid;
             c->pendWg = wgPerCU;

@@ -1777,8 +1777,42 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
     return W_CONTINUE;
 }
 
-// ONE: the build with one row slot per lane -- a QP whose free set outgrows 63 variables is handed over.
-template <bool ONE>
+// The second row slot (rows 64..127) parked in global scratch: park[f * 64 + lane], f = field
+[[maybe_unused]] constexpr int PARK_FIELDS = 6 + NR;
+__device__ __forceinline__ void slot1_store(const Rows &R, double *park) {
+    const int lane = lane_id();
+    park[0 * 64 + lane] = __hiloint2double(R.rank[1], R.ord[1]);
+    park[1 * 64 + lane] = R.zF[1];
+    park[2 * 64 + lane] = R.ur[1];
+    park[3 * 64 + lane] = R.dr[1];
+    park[4 * 64 + lane] = R.dg[1];
+    park[5 * 64 + lane] = R.rd[1];
+#pragma unroll
+    for (int w = 0; w < NR; ++w) park[(6 + w) * 64 + lane] = R.Y[w][1];
+}
+__device__ __forceinline__ void slot1_load(Rows &R, const double *park) {
+    const int lane = lane_id();
+    const double oi = park[0 * 64 + lane];
+    R.ord[1] = __double2loint(oi);
+    R.rank[1] = __double2hiint(oi);
+    R.zF[1] = park[1 * 64 + lane];
+    R.ur[1] = park[2 * 64 + lane];
+    R.dr[1] = park[3 * 64 + lane];
+    R.dg[1] = park[4 * 64 + lane];
+    R.rd[1] = park[5 * 64 + lane];
+#pragma unroll
+    for (int w = 0; w < NR; ++w) R.Y[w][1] = park[(6 + w) * 64 + lane];
+}
+__device__ __forceinline__ void slot1_reset(Rows &R) {  // the values every QP starts with
+    R.ord[1] = 0; R.rank[1] = 0;
+    R.zF[1] = R.ur[1] = R.dr[1] = 0.0;
+    R.dg[1] = 1.0; R.rd[1] = 1.0;
+#pragma unroll
+    for (int w = 0; w < NR; ++w) R.Y[w][1] = 0.0;
+}
+
+// PARK: the build that keeps the second row slot in global scratch between the passes that need it.
+template <bool PARK>
 __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, const WLds &L, double *gscr) {
     const int lane = lane_id();
     const int N = P.N, M = P.M, J = P.J, MJ = P.MJ;
@@ -1845,6 +1879,8 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     S.blkDz = 0.0;
     S.certMask = 0u;
     S.appAll = true;
+    double *park = gscr + WAVE_LS_DOUBLES + 128 * 64;
+    if (PARK) slot1_store(S.R, park);
     for (int e = lane; e < NR * NR; e += 64) L.H[e] = 0.0;
     for (int e = lane; e < MJX * MJX; e += 64) L.GG[e] = 0.0;
     wave_sync();
@@ -1878,62 +1914,81 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
                 nin += __popcll(__ballot(2 * lane + 128 * (k >> 1) < N && st_of(S.Sp, k) == SSQP_IN));
             Knew = nin;
         }
-        if (Knew > C.RC || (ONE && Knew > 63)) {
+        if (Knew > C.RC) {
             handover = true;
             break;
         }
-        const bool two = !ONE && ((S.K > 63) || (Knew > 63));
-        int act;
-        if (two) act = wave_sync_factor<2>(C, L, S);
-        else act = wave_sync_factor<1>(C, L, S);
-        if (act == W_BREAK) break;
-        if (act == W_HANDOVER) {
-            handover = true;
-            break;
-        }
-        const int K = S.K;
-        if (K == 0) {  // ---------------------------------------- freeK!  SSQP.jl:35-59
-            // p = V z + q: with no free variable this is the cached hq
-            int flag = 0;
-            double pa = 0.0;
-            unsigned rel = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = 2 * lane + 128 * (k >> 1) + (k & 1);
-                const double pp = (k & 1) ? S.hq[k >> 1].y : S.hq[k >> 1].x;
-                const int s = st_of(S.Sp, k);
-                if (i < N && ((pp >= -tol && s == SSQP_UP) || (pp <= tol && s == SSQP_DN))) {  // :41-47
-                    flag = 1;
-                    pa = fmax(pa, fabs(pp));
-                    rel |= 1u << k;
-                }
-            }
-            C.sBytes += 8ll * N * N + 16ll * N + 4ll * (N + J);
-            C.sFlops += 2ll * N * N;
-            const bool any = __ballot(flag) != 0ull;
-            bool done = !any;
-            if (any) {
-                const double pm = wave_max(pa);
-                if (pm <= tol) done = true;  // all movable are optimal: statuses restored (:52-55)
-            }
-            if (done) {
-                if (trace && lane == 0) *trace = ssqp_trace{0, 0, 3, 0};
-                C.ret = C.iter;  // SSQP.jl:281 (no polishSz! on this exit)
+        const bool two = (S.K > 63) || (Knew > 63);
+        // PARK (the 256-register build): the second row slot is in registers only during a pass that has more than 63
+        // rows -- under a tenth of the passes of the headline workload; between passes it is parked in the wavefront's
+        // global scratch and the registers hold constants, so the one-slot passes are allocated as if it did not exist
+        if (PARK && two) slot1_load(S.R, park);
+        int step = 0;  // 0: next pass, 1: done, 2: hand over
+        do {
+            int act;
+            if (two) act = wave_sync_factor<2>(C, L, S);
+            else act = wave_sync_factor<1>(C, L, S);
+            if (act == W_BREAK) {
+                step = 1;
                 break;
             }
+            if (act == W_HANDOVER) {
+                step = 2;
+                break;
+            }
+            const int K = S.K;
+            if (K == 0) {  // ---------------------------------------- freeK!  SSQP.jl:35-59
+                // p = V z + q: with no free variable this is the cached hq
+                int flag = 0;
+                double pa = 0.0;
+                unsigned rel = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if ((rel >> k) & 1u) S.Sp &= ~(15u << (4 * k));  // -> IN (code 0)
-            S.appAll = true;
-            S.hbValid = false;  // variables with z != 0 may have left B
-            if (trace && lane == 0) *trace = ssqp_trace{0, 0, 0, 0};
-            continue;
+                for (int k = 0; k < 8; ++k) {
+                    const int i = 2 * lane + 128 * (k >> 1) + (k & 1);
+                    const double pp = (k & 1) ? S.hq[k >> 1].y : S.hq[k >> 1].x;
+                    const int s = st_of(S.Sp, k);
+                    if (i < N && ((pp >= -tol && s == SSQP_UP) || (pp <= tol && s == SSQP_DN))) {  // :41-47
+                        flag = 1;
+                        pa = fmax(pa, fabs(pp));
+                        rel |= 1u << k;
+                    }
+                }
+                C.sBytes += 8ll * N * N + 16ll * N + 4ll * (N + J);
+                C.sFlops += 2ll * N * N;
+                const bool any = __ballot(flag) != 0ull;
+                bool done = !any;
+                if (any) {
+                    const double pm = wave_max(pa);
+                    if (pm <= tol) done = true;  // all movable are optimal: statuses restored (:52-55)
+                }
+                if (done) {
+                    if (trace && lane == 0) *trace = ssqp_trace{0, 0, 3, 0};
+                    C.ret = C.iter;  // SSQP.jl:281 (no polishSz! on this exit)
+                    step = 1;
+                    break;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if ((rel >> k) & 1u) S.Sp &= ~(15u << (4 * k));  // -> IN (code 0)
+                S.appAll = true;
+                S.hbValid = false;  // variables with z != 0 may have left B
+                if (trace && lane == 0) *trace = ssqp_trace{0, 0, 0, 0};
+                break;  // (next pass)
+            }
+            if (K > C.maxK) C.maxK = K;
+            if (two) act = wave_pass<2>(C, L, S, gscr);
+            else act = wave_pass<1>(C, L, S, gscr);
+            step = (act == W_BREAK) ? 1 : 0;
+    
+        } while (0);
+        if (PARK && two) {
+            slot1_store(S.R, park);
+            slot1_reset(S.R);
         }
-        if (K > C.maxK) C.maxK = K;
-        if (two) act = wave_pass<2>(C, L, S, gscr);
-        else act = wave_pass<1>(C, L, S, gscr);
-        if (act == W_BREAK) break;
+        if (step == 2) handover = true;
+        if (step != 0) break;
     }
+    if (PARK && S.K > 64) slot1_load(S.R, park);  // (the rows are written out below)
 
     // ---- results: z (free variables from their rows, bound ones from the dense copy / the bounds), S, status
     const bool polished = (C.ret > 0) && (S.K > 0);
@@ -1992,12 +2047,9 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
             P.fbIter[prob] = C.iter - 1;  // passes completed
             const unsigned slot = atomicAdd(P.fbCount, 1u);
             P.fbList[slot] = prob;
-            (void)atomicAdd(P.queue + 5, (unsigned)(C.iter - 1));  // (for the host's choice of the build: how late
-        } else {                                                   //  hand-overs come, see ssqp_api.hip)
+        } else {
             P.status[prob] = C.ret;
             if (P.detail) P.detail[prob] = C.det;
-            (void)atomicAdd(P.queue + 6, (unsigned)(C.iter > P.maxIter ? P.maxIter : C.iter));
-            (void)atomicAdd(P.queue + 7, 1u);
         }
     }
     wave_sync();
@@ -2006,11 +2058,13 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
 // Two builds of the kernel, one per translation unit (SSQP_WAVE_VARIANT) so that they compile side by side:
 //   0: <1, false>  one wavefront per SIMD -- four QPs per CU, 512 registers, up to ~90 free variables, the whole
 //                  factor in LDS;
-//   1: <2, true>   two per SIMD -- eight QPs per CU, 256 registers, one row slot per lane: at most 63 free variables.
-// Either hands a QP that outgrows it over to the workgroup kernel.  Under one per cent of the passes of the headline
-// workload have more than 63 free variables, and carrying the second row slot through every pass would cost the
-// 256-register build some 130 spilled registers (measured: a tenth of its throughput).
-template <int WPS, bool ONE>
+//   1: <2, true>   two per SIMD -- eight QPs per CU, 256 registers, 20 KiB of LDS: rows >= 64 of the factor live in the
+//                  wavefront's global scratch (L2), and so does the second row slot between the passes that use it
+//                  (PARK).  Half of the QPs of the headline workload end with 64-79 free variables, but only in their
+//                  last tenth: carrying the second slot's 36 registers through every pass cost this build some 130
+//                  spilled registers and a tenth of its throughput.
+// Either hands a QP that outgrows it over to the workgroup kernel.
+template <int WPS, bool PARK>
 __global__ __launch_bounds__(64, WPS) void ssqp_wave_kernel(SolveParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WLds L;
@@ -2020,9 +2074,9 @@ __global__ __launch_bounds__(64, WPS) void ssqp_wave_kernel(SolveParams P) {
         const int r1 = rc > 64 ? rc - 64 : 0;
         int o = 0;
         L.F.L0 = d0 + o; o += 2080;
-        if (ONE) {  // (no rows >= 64)
-            L.F.L1 = d0;
-            L.F.R1 = 1;
+        if (PARK) {
+            L.F.L1 = P.wscratch + (size_t)blockIdx.x * P.wscratchStride + WAVE_LS_DOUBLES;
+            L.F.R1 = 64;
         } else {
             L.F.L1 = d0 + o; o += rc * r1 + 2;
             L.F.R1 = r1 > 0 ? r1 : 1;
@@ -2041,7 +2095,7 @@ __global__ __launch_bounds__(64, WPS) void ssqp_wave_kernel(SolveParams P) {
         if (threadIdx.x == 0) prob = (int)atomicAdd(P.queue, 1u);
         prob = __builtin_amdgcn_readfirstlane(prob);
         if (prob >= P.nprob) break;
-        wave_solve_one<ONE>(P, prob, L, gscr);
+        wave_solve_one<PARK>(P, prob, L, gscr);
     }
 }
 
@@ -2085,7 +2139,7 @@ hipError_t launch_wave_v1(const SolveParams &P, int grid, hipStream_t stream);
 bool wave_kernel_applies(int N, int M, int J) {
     return (N % 2 == 0) && N >= 2 && N <= WAVE_MAXN && (M + J) <= WAVE_MJ;
 }
-int wave_lds_bytes(int rc) {  // rc <= 0: the one-slot build (no rows >= 64)
+int wave_lds_bytes(int rc) {  // rc <= 0: the eight-per-CU build (rows >= 64 in global scratch)
     const int r1 = rc > 64 ? rc - 64 : 0;
     const int l1 = rc > 0 ? rc * r1 + 2 : 0;
     const int dbl = 2080 + l1 + NR * NR + 2 * (MJX * MJX + 1) + 16 * 3 + 8;
@@ -2093,7 +2147,9 @@ int wave_lds_bytes(int rc) {  // rc <= 0: the one-slot build (no rows >= 64)
 }
 size_t wave_scratch_doubles(int N, int M, int J) {
     (void)N; (void)M; (void)J;
-    return (size_t)WAVE_LS_DOUBLES + 64;  // least-squares scratch of the purged-row multipliers
+    // least-squares scratch, then (eight-per-CU build) rows 64..127 of up to 128 columns of the factor and the parked
+    // second row slot
+    return (size_t)WAVE_LS_DOUBLES + 128 * 64 + PARK_FIELDS * 64 + 64;
 }
 hipError_t launch_solve_wave(const SolveParams &P, int grid, int variant, hipStream_t stream) {
     if (variant == 1) return launch_wave_v1(P, grid, stream);

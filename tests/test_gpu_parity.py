@@ -419,29 +419,26 @@ def test_wide_n_kernels(pkg, orc, N):
     run_cfg(pkg, orc, cfg, 2, seed0=1234 + N)
 
 
-def test_one_slot_build_falls_back_when_free_sets_outgrow_it(pkg, orc):
-    """a batch above 4 QPs per CU goes to the eight-per-CU build (at most 63 free variables) by default; here every QP
-    ends with 70-82 free variables, so that build hands all of them over -- the context sees the count and gives the
-    next batch of the shape to the all-rows build, which finishes them itself.  Same results either way."""
-    ctx = pkg.default_context()
+def test_eight_per_cu_build_parks_second_row_slot(pkg, orc):
+    """a batch above 4 QPs per CU goes to the eight-per-CU build by default; here every QP ends with 70-82 free variables:
+    rows 64.. live in the second row slot, which that build keeps in global scratch between passes -- same results as
+    the four-per-CU build, nothing handed over"""
     import torch
+    ctx = pkg.default_context()
     ncu = torch.cuda.get_device_properties(ctx.device).multi_processor_count
     nprob = 4 * ncu + 40
     cfg = pkg.GenConfig(88, 1, 0, 176, 1e-3, 0.0, 1.2, 0.0)
     prob = pkg.generate_batch(cfg, nprob, 4242)
     x0, S0, st = pkg.phase1_batch(prob)
     assert (st == 1).all()
-    own = pkg.Context(ctx.device)                   # (a fresh context: no memory of earlier batches)
-    z1, S1, st1, d1, stats1 = pkg.solveQP_batch(prob, S0, x0, ctx=own, want_stats=True)
-    z2, S2, st2, d2, stats2 = pkg.solveQP_batch(prob, S0, x0, ctx=own, want_stats=True)
-    assert ((stats1["path"] & 48) == 48).all()      # wavefront kernel, then handed over
-    assert ((stats2["path"] & 48) == 16).all()      # wavefront kernel to the end
-    assert stats1["max_k"].min() > 63 and stats1["max_k"].max() <= 88
+    z1, S1, st1, d1, stats1 = pkg.solveQP_batch(prob, S0, x0, want_stats=True)
+    with ctx.options(wave_qp_per_cu=4):
+        z2, S2, st2, d2, stats2 = pkg.solveQP_batch(prob, S0, x0, want_stats=True)
+    for stats in (stats1, stats2):
+        assert ((stats["path"] & 48) == 16).all()   # wavefront kernel to the end
+        assert stats["max_k"].min() > 63 and stats["max_k"].max() <= 88
     assert np.array_equal(S1, S2) and np.array_equal(st1, st2)
     assert np.allclose(z1, z2, rtol=1e-12, atol=1e-14)
-    with own.options(wave_qp_per_cu=8):             # said explicitly, the choice is the caller's
-        z3, S3, st3, d3, stats3 = pkg.solveQP_batch(prob, S0, x0, ctx=own, want_stats=True)
-    assert ((stats3["path"] & 48) == 48).all() and np.array_equal(S1, S3) and np.array_equal(st1, st3)
     sub = {k: np.ascontiguousarray(v[:48]) for k, v in prob.items()}
     zo, So, sto, _, _ = oracle_batch(orc, sub, S0[:48], x0[:48])
     assert_parity(z1[:48], S1[:48], st1[:48], zo, So, sto)
