@@ -27,8 +27,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# vector-instruction issue: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles per SIMD (SIMD-32) at 2.4 GHz
-VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
+# vector-instruction issue: 256 CUs x 4 SIMDs at 2.4 GHz, one wave64 f64 VALU instruction per 4 cycles per SIMD (16 f64
+# lanes per cycle = the 78.6 TFLOP/s vector-f64 figure; the SQ counters agree: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.05
+# quad-cycles per instruction for this kernel)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0
 KERNEL_SOURCES = ["ssqp_wave.hip", "ssqp_kernels.hip", "ssqp_device.h", "ssqp_internal.h", "ssqp_api.hip"]
 
 
@@ -298,8 +300,12 @@ def run(args):
                      "wait_frac": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
                      "valu_per_pass": sq["SQ_INSTS_VALU"] / float(iters.sum()),
                      "salu_per_pass": sq["SQ_INSTS_SALU"] / float(iters.sum()),
-                     "note": "SQ counters per launch from profiles/ (same kernel source hash) / this run's kernel time; "
-                             "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction"}
+                     "achieved_timed_region": sq["SQ_INSTS_VALU"] / (elapsed / args.steps),
+                     "frac_timed_region": sq["SQ_INSTS_VALU"] / (elapsed / args.steps) / VALU_ISSUE_PEAK,
+                     "note": "SQ counters per launch from profiles/ (same kernel source hash; serial four-per-CU launch) / "
+                             "this run's kernel time; *_timed_region: / the wall time per step of the timed region (launch "
+                             "lanes, eight per CU: same instruction stream per QP up to the parked row slot); peak = 256 "
+                             "CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 f64 VALU instruction"}
         out = {
             "metric": "QPs/sec (batched N=512 dense portfolio QP, solveQP(Q,S,x0) to KKT)",
             "value": qps, "unit": "QPs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

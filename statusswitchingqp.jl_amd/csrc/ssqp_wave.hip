@@ -738,13 +738,13 @@ __device__ __forceinline__ void gg_rank1(const WLds &L, double sign) {
 // appended to F or a row leaves E, so a certificate stays valid across such passes (WState::certMask).
 // Lane i holds row i of the W0 x W0 Gram matrix of the active rows (row-id order, ids in L.ra).
 template <int WM>
-__device__ __forceinline__ bool full_rank_certified(const WLds &L, int W0) {
+__device__ __forceinline__ bool full_rank_certified(const WLds &L, int W0, int raLane) {
     const int lane = lane_id();
-    const int ri = L.ra[lane < W0 ? lane : 0];
+    const int ri = lane < W0 ? raLane : 0;  // raLane: L.ra[lane], the row id of position `lane`
     double a[WM];
 #pragma unroll
     for (int c = 0; c < WM; ++c) {
-        const int rc = L.ra[c < W0 ? c : 0];
+        const int rc = __builtin_amdgcn_readlane(raLane, c < W0 ? c : 0);
         const double v = L.GG[ri * MJX + rc];
         a[c] = (lane < W0 && c < W0) ? v : 0.0;
     }
@@ -753,7 +753,7 @@ __device__ __forceinline__ bool full_rank_certified(const WLds &L, int W0) {
     for (int c = 0; c < WM; ++c) {
         if (c < W0) {  // uniform
             const double d = readlane_f64(a[c], c);
-            const int rc = L.ra[c];
+            const int rc = __builtin_amdgcn_readlane(raLane, c);
             const double thr = fmax(1e-8, 1e-6 * L.GG[rc * MJX + rc]);
             if (!(d > thr)) ok = false;
             const double r = fast_rcp(d > thr ? d : 1.0);
@@ -775,13 +775,13 @@ __device__ __forceinline__ bool full_rank_certified(const WLds &L, int W0) {
 // the pivot row with v_readlane; the unit-lower factor goes to `tr` column by column so that the back substitution
 // needs one broadcast per step.  Returns false when a pivot is not > 0 (cholesky(C) of the reference throws).
 template <int WM>
-__device__ __forceinline__ bool schur_solve(const WLds &L, double bEv, int W, double &lam) {
+__device__ __forceinline__ bool schur_solve(const WLds &L, double bEv, int W, double &lam, int raLane) {
     const int lane = lane_id();
-    const int ri = L.ra[lane < W ? lane : 0];
+    const int ri = lane < W ? raLane : 0;  // raLane: L.ra[lane]
     double a[WM];
 #pragma unroll
     for (int c = 0; c < WM; ++c) {
-        const int rc = L.ra[c < W ? c : 0];
+        const int rc = __builtin_amdgcn_readlane(raLane, c < W ? c : 0);
         const double v = L.H[ri * NR + rc];
         a[c] = (lane < W && c < W) ? v : 0.0;
     }
@@ -1229,13 +1229,16 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
         if (lane < MJX && ((act >> lane) & 1u)) L.ra[__popc(below)] = (int16_t)lane;
     }
     wave_sync();
+    // register copies of the two small LDS tables the pass keeps asking for (one read each instead of one per use):
+    // raLane = L.ra[lane] (row id of kept position `lane`), alRow = L.aLrow[lane] (alphaL of row id `lane`, set below)
+    int raLane = L.ra[lane < MJX ? lane : 0];
     if (W0 > 0) {
         // usually the Gram matrix of the active rows proves that the filter cannot purge anything
         bool certified = (act & ~S.certMask) == 0u;  // (a subset of a certified row set with no column lost since)
         if (!certified && K >= W0) {
-            if (W0 > 8) certified = full_rank_certified<MJX>(L, W0);
-            else if (W0 > 4) certified = full_rank_certified<8>(L, W0);
-            else certified = full_rank_certified<4>(L, W0);
+            if (W0 > 8) certified = full_rank_certified<MJX>(L, W0, raLane);
+            else if (W0 > 4) certified = full_rank_certified<8>(L, W0, raLane);
+            else certified = full_rank_certified<4>(L, W0, raLane);
             S.certMask = certified ? act : 0u;
         }
         if (!certified) {
@@ -1245,6 +1248,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
                 const unsigned below = kept & ((1u << (lane & 31)) - 1u);
                 if (lane < MJX && ((kept >> lane) & 1u)) L.ra[__popc(below)] = (int16_t)lane;
                 wave_sync();
+                raLane = L.ra[lane < MJX ? lane : 0];
             }
         }
     }
@@ -1254,18 +1258,19 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
     if (W > 0) {
         double lam = 0.0;
         bool okH = true;
-        if (W > 8) okH = schur_solve<MJX>(L, S.bEv, W, lam);
-        else if (W > 6) okH = schur_solve<8>(L, S.bEv, W, lam);
-        else if (W > 4) okH = schur_solve<6>(L, S.bEv, W, lam);
-        else okH = schur_solve<4>(L, S.bEv, W, lam);
+        if (W > 8) okH = schur_solve<MJX>(L, S.bEv, W, lam, raLane);
+        else if (W > 6) okH = schur_solve<8>(L, S.bEv, W, lam, raLane);
+        else if (W > 4) okH = schur_solve<6>(L, S.bEv, W, lam, raLane);
+        else okH = schur_solve<4>(L, S.bEv, W, lam, raLane);
         if (!okH) {  // cholesky(C) of the reference throws (SSQP.jl:328)
             C.ret = -1;
             C.det = SSQP_DETAIL_POSDEF_C;
             return W_BREAK;
         }
-        if (lane < W) L.aLrow[L.ra[lane]] = -lam;
+        if (lane < W) L.aLrow[raLane] = -lam;
         wave_sync();
     }
+    const double alRow = L.aLrow[lane < MJX ? lane : 0];
     WPH(1);  // Schur gather + lambda
     // ---- alpha = -V_FF^-1 (AE' alphaL + c):  v = D^-1 (Y_A alphaL + y_c), alpha = -L'^-1 v   (SSQP.jl:329-331)
     double v[2] = {0.0, 0.0};
@@ -1274,7 +1279,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
 #pragma unroll
     for (int w = 0; w < MJX; ++w) {
         if ((kept >> w) & 1u) {  // uniform
-            const double al = L.aLrow[w];
+            const double al = readlane_f64(alRow, w);
 #pragma unroll
             for (int t = 0; t < SL; ++t) v[t] = fma(R.Y[w][t], al, v[t]);
         }
@@ -1335,7 +1340,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
             Ga = L.H[wl * NR + CC];
 #pragma unroll
             for (int a = 0; a < MJX; ++a)
-                if ((kept >> a) & 1u) Ga = fma(L.H[wl * NR + a], L.aLrow[a], Ga);  // uniform
+                if ((kept >> a) & 1u) Ga = fma(L.H[wl * NR + a], readlane_f64(alRow, a), Ga);  // uniform
             Ga = -Ga;
         }
         const double po = Ga - S.gz, zo = S.bEv - S.gz;
@@ -1447,9 +1452,9 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
                     col[c] = C.V + (size_t)rbcast_i<SL>(R.ord, e) * N;
                     wj[c] = rbcast<SL>(alpha, e);
                 } else {
-                    const int rid = L.ra[e - K];
+                    const int rid = __builtin_amdgcn_readlane(raLane, e - K);
                     col[c] = C.Ct + (size_t)rid * N;
-                    wj[c] = L.aLrow[rid];
+                    wj[c] = readlane_f64(alRow, rid);
                 }
                 wj[c] = (e0 + c < ncolG) ? wj[c] : 0.0;
             }
@@ -1461,14 +1466,11 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
                 for (int c = 0; c < NB; ++c) vv[m][c] = *reinterpret_cast<const double2 *>(col[c] + (rr < N ? rr : 0));
             }
 #pragma unroll
-            for (int m = 0; m < NCH; ++m) {
-                const int rr = 2 * lane + 128 * m;
-                const double keep = (rr < N) ? 1.0 : 0.0;
+            for (int m = 0; m < NCH; ++m) {  // (lanes beyond N accumulate finite junk from element 0: KKTchk! skips them)
 #pragma unroll
                 for (int c = 0; c < NB; ++c) {
-                    const double wk = wj[c] * keep;
-                    gam[m].x = fma(vv[m][c].x, wk, gam[m].x);
-                    gam[m].y = fma(vv[m][c].y, wk, gam[m].y);
+                    gam[m].x = fma(vv[m][c].x, wj[c], gam[m].x);
+                    gam[m].y = fma(vv[m][c].y, wj[c], gam[m].y);
                 }
             }
         }
@@ -1499,7 +1501,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
     if (S.Emask != 0u) {  // multipliers of the active inequalities (:149-171)
         if (kept == act) {  // every active row kept its own multiplier
             if (lane >= M && lane < MJ && ((act >> lane) & 1u)) {
-                const double Lda = L.aLrow[lane];
+                const double Lda = alRow;
                 if (Lda < -tolG) ev = keymin(ev, KeyMin{Lda, N + lane - M});
             }
         } else {
