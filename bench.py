@@ -276,6 +276,8 @@ def run(args):
     traffic = pmc[key].get("hbm_bytes_per_launch") if pmc and key in pmc else None
     traffic_dense = pmc["dense_formulation"].get("hbm_bytes_per_launch") if pmc and "dense_formulation" in pmc else None
     sq = pmc[key].get("sq") if pmc and key in pmc else None
+    traffic8 = (pmc["eight_per_cu_build"].get("hbm_bytes_per_launch")
+                if pmc and "eight_per_cu_build" in pmc and qpc_lanes == 8 and not args.dense else None)
 
     out = None
     if rank == 0:
@@ -287,11 +289,18 @@ def run(args):
                 "kernel_ms": k_ms, "alg_bytes_per_launch": read_bytes,
                 "achieved_from_traffic": None if traffic is None else traffic / (k_ms * 1e-3) / 1e9,
                 "frac_from_traffic": None if traffic is None else traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "note": "achieved = bytes this formulation reads (counted in-kernel, L2/MALL hits included) / kernel time; "
-                        "achieved_from_traffic = PMC HBM bytes / kernel time.  The default formulation (kept LDL' factor, "
-                        "cached hq/bE/Schur block, gamma pass over the free columns only) is bound by dependent "
-                        "single-wavefront chains, not by HBM: see roofline_issue; the HBM-bound formulation of the same "
-                        "path is roofline_dense_formulation"}
+                # the timed region itself (launch lanes overlap, so per-launch durations do not add up): bytes of all
+                # its launches / its wall time
+                "achieved_timed_region": world * read_bytes * args.steps / elapsed / 1e9,
+                "frac_timed_region": read_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
+                "traffic_timed_region_build": traffic8,
+                "note": "achieved = bytes this formulation reads (counted in-kernel, L2/MALL hits included) / kernel time of "
+                        "ONE serial launch (four QPs per CU: bound by its dependent single-wavefront chains, see "
+                        "roofline_issue); achieved_from_traffic = PMC bytes (L2 misses: FETCH_SIZE x2 + WRITE_SIZE) / the same "
+                        "time.  *_timed_region = the bytes of all launches of the timed region / its wall time: with launch "
+                        "lanes (eight QPs per CU, overlapping launches) the same formulation moves its bytes at that rate, "
+                        "which is where HBM starts to bound it (about 6.3 TB/s are achievable).  The reference-shaped "
+                        "formulation of the same path is roofline_dense_formulation"}
         issue = None
         if sq:
             issue = {"bound": "valu-issue", "achieved": sq["SQ_INSTS_VALU"] / (k_ms * 1e-3), "peak": VALU_ISSUE_PEAK,

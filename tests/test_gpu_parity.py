@@ -477,7 +477,7 @@ def test_long_runs_refresh_caches(pkg, orc):
     zo, So, sto, _, _ = oracle_batch(orc, sub, S0[ok], x0[ok])
     assert (sto > 150).any()
     ctx = pkg.default_context()
-    for opts in (dict(), dict(wave_kernel=0)):
+    for opts in (dict(), dict(wave_kernel=0), dict(wave_qp_per_cu=8)):
         with ctx.options(**opts):
             z, S, status, detail = pkg.solveQP_batch(sub, S0[ok], x0[ok])
         assert_parity(z, S, status, zo, So, sto)

@@ -10,12 +10,15 @@ tag = sys.argv[1]
 base = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 
 
-def per_launch(passdir):
-    """{counter: mean over launches of the sum over the solve kernels of one launch}"""
+def per_launch(passdir, only=None):
+    """{counter: mean over launches of the sum over the solve kernels of one launch}; only = substring a kernel name
+    must contain"""
     acc = collections.defaultdict(lambda: collections.defaultdict(list))   # counter -> kernel -> values per dispatch
     for f in glob.glob(os.path.join(base, passdir, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             kn = r["Kernel_Name"]
+            if only is not None and only not in kn:
+                continue
             if "ssqp_solve_kernel" in kn or "ssqp_wave_kernel" in kn:
                 acc[r["Counter_Name"]]["wave" if "wave" in kn else "wg"].append(float(r["Counter_Value"]))
     out = {}
@@ -39,5 +42,11 @@ for p in ("pmc_sq1_default", "pmc_sq2_default", "pmc_sq3_default"):
     sq.update(per_launch(p))
 if sq and "default_formulation" in res:
     res["default_formulation"]["sq"] = sq
+# the eight-per-CU build (what the launch lanes of the timed region run), from the lanes passes
+f8 = per_launch("pmc_fetch_lanes", "ssqp_wave_kernel<2, true>").get("FETCH_SIZE")
+w8 = per_launch("pmc_write_lanes", "ssqp_wave_kernel<2, true>").get("WRITE_SIZE")
+if f8 is not None and w8 is not None:
+    res["eight_per_cu_build"] = {"FETCH_SIZE_KiB": f8, "WRITE_SIZE_KiB": w8, "hbm_bytes_per_launch": (2.0 * f8 + w8) * 1024.0,
+                                 "sq": per_launch("pmc_sq1_lanes", "ssqp_wave_kernel<2, true>")}
 json.dump(res, open(os.path.join(base, "pmc_counters.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -20,5 +20,10 @@ run write_dense   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 run sq1_default   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc_sq1_default -- $B --steps 1 --warmup 0
 run sq2_default   rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2_default -- $B --steps 1 --warmup 0
 run sq3_default   rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_INSTS_BRANCH SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq3_default -- $B --steps 1 --warmup 0
+# the eight-per-CU build of the timed region (launch lanes); counter collection serialises the launches
+L="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --skip-dense --streams 3 --steps 3 --warmup 0"
+run fetch_lanes   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_lanes -- $L
+run write_lanes   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_lanes -- $L
+run sq1_lanes     rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc_sq1_lanes -- $L
 python3 $GRAFT_REPO_ROOT/tools/pmc_to_json.py $TAG
 find $OUT -name "*kernel_stats.csv"
