@@ -8,9 +8,9 @@
 //   * no workgroup barrier anywhere -- all exchanges are DPP / v_readlane / ds_bpermute inside the wavefront;
 //   * four (or more) independent QPs per CU, one or two per SIMD, so every SIMD always has its own chain to run;
 //   * everything that belongs to a free variable lives in the REGISTERS of "its" lane (row r of the kept factor
-//     = lane r & 63 of slot r >> 6): z, bounds, its column of [A;G], the forward-substituted border rows Y;
-//   * N-vectors (hq = V[:,nz(zB)] zB + q, z, S, gamma) live in registers too, 8 doubles per lane (N <= 512);
-//   * LDS holds only the kept LDL' factor of V[F,F] and the 12 x 12 Schur block;
+//     = lane r & 63 of slot r >> 6): index, rank, z, bounds, pivot, the forward-substituted border rows Y;
+//   * N-vectors (hq = V[:,nz(zB)] zB + q, S, gamma) live in registers too, 8 doubles per lane (N <= 512);
+//   * LDS holds only the kept LDL' factor of V[F,F], the 12 x 12 Schur block and the Gram matrix of the border rows;
 //   * the Schur block H = [AE; c'] V_FF^-1 [AE' c] is kept across passes for ALL rows of [A;G]: an appended free
 //     variable adds one rank-1 term, a deleted one removes one (H -= g g'/m, the block-inverse identity), so a
 //     change of the active inequality set costs nothing and no pass re-forms H from the factor.
