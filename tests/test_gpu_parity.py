@@ -445,6 +445,38 @@ def test_eight_per_cu_build_parks_second_row_slot(pkg, orc):
     assert_parity(z2[:48], S2[:48], st2[:48], zo, So, sto)
 
 
+@pytest.mark.parametrize("shape", ["deep", "boundary"])
+def test_second_row_slot_with_active_inequalities(pkg, orc, shape):
+    """free sets that live in the second row slot of the wavefront kernel: "deep" ends with 105-120 free variables and
+    ~6 active inequalities (the eight-per-CU build finishes it with the parked slot, the four-per-CU build hands over at
+    its 92 rows); "boundary" ends with 54-77 and upper bounds that block, so appends AND deletes cross row 64 in both
+    directions.  Every build against the oracle."""
+    if shape == "deep":
+        cfg = pkg.GenConfig(128, 1, 8, 256, 1e-3, 0.0, 0.98, 0.0)
+    else:
+        cfg = pkg.GenConfig(144, 1, 5, 288, 1e-3, 0.03, 1.0, 0.02)
+    prob = pkg.generate_batch(cfg, 48, 777 + SEED_SHIFT)
+    x0, S0, st = pkg.phase1_batch(prob)
+    ok = st == 1
+    assert ok.sum() >= 24
+    sub = {k: np.ascontiguousarray(v[ok]) for k, v in prob.items()}
+    zo, So, sto, _, _ = oracle_batch(orc, sub, S0[ok], x0[ok])
+    assert (sto > 0).all()
+    ctx = pkg.default_context()
+    for opts in (dict(wave_qp_per_cu=8), dict(wave_qp_per_cu=4), dict(wave_kernel=0)):
+        with ctx.options(**opts):
+            z, S, status, detail, stats = pkg.solveQP_batch(sub, S0[ok], x0[ok], want_stats=True)
+        assert_parity(z, S, status, zo, So, sto)
+        if shape == "deep" and SEED_SHIFT == 0:
+            assert stats["max_k"].min() > 100 and stats["max_k"].max() <= 127
+            if opts.get("wave_qp_per_cu") == 8:
+                assert ((stats["path"] & 48) == 16).all()    # the wavefront kernel to the end
+            if opts.get("wave_qp_per_cu") == 4:
+                assert ((stats["path"] & 48) == 48).all()    # handed over beyond 92 rows
+        if shape == "boundary" and SEED_SHIFT == 0 and "wave_kernel" not in opts:
+            assert (stats["max_k"] > 64).any() and ((stats["path"] & 32) == 0).all()
+
+
 def test_two_contexts_one_device_agree_with_one(pkg, orc):
     """ssqp_solve_batch_multi_f64: contiguous blocks over two contexts (here both on device 0, each with its own
     host thread, stream and workspace) give exactly the single-context results"""
