@@ -120,9 +120,10 @@ def run(args):
     ctx = pkg.Context(local)
     if args.dense:
         ctx.set_option("dense_gamma", 1)
-    # several launch lanes on one GPU: the (normally empty) hand-over launch is issued lazily, see include/ssqp_hip.h.
-    # With more than one rank the gather consumes the results stream-ordered, so everything stays queued.
-    lazy = 1 if (world == 1 and args.streams > 1) else 0
+    # several launch lanes on one GPU: the (normally empty) hand-over launch is issued lazily, see include/ssqp_hip.h:
+    # a lane's results are complete once its context was flushed (which the next solve on the lane does anyway), so
+    # with more than one rank the gather of a step is issued when its lane comes round again, right after that flush
+    lazy = 1 if args.streams > 1 else 0
     ctx.set_option("lazy_handover", lazy)
     # wavefronts per CU of the wavefront kernel: with several batches in flight two per SIMD (8 per CU) give more QPs/s;
     # a single 1024-QP launch fills 4 per CU exactly and runs fastest with one per SIMD (include/ssqp_hip.h)
@@ -151,18 +152,38 @@ def run(args):
         lanes.append((batch.twin(c2), torch.cuda.Stream(dev)))
     comm = torch.cuda.Stream(dev) if world > 1 else None   # the ONE stream every gather is issued from
     step_no = [0]
+    owed = [False] * nlanes                 # lanes whose last solve has not been gathered yet
+    gathers = [0]
+
+    def gather(i):
+        """final gather of lane i's step (RCCL over xGMI), issued from the one communication stream in launch order;
+        the lane's next solve waits for it (it overwrites the buffers the gather reads)"""
+        b, st = lanes[i]
+        if not owed[i]:
+            return
+        b.ctx.flush()                       # (lazy hand-over: an owed workgroup-kernel launch goes out first)
+        comm.wait_stream(st)
+        with torch.cuda.stream(comm):
+            pkg.dist.gather_results(b.z, b.S, b.status)
+        st.wait_stream(comm)
+        owed[i] = False
+        gathers[0] += 1
 
     def step():
-        b, st = lanes[step_no[0] % nlanes]
+        i = step_no[0] % nlanes
+        b, st = lanes[i]
         step_no[0] += 1
+        if world > 1:
+            gather(i)                       # the step this lane ran last time round
         with torch.cuda.stream(st):
             b.solve()                       # in-kernel active-set loop, asynchronous on the lane's stream
-        if world > 1:                       # final gather of the sharded batch (RCCL over xGMI), in launch order
-            comm.wait_stream(st)
-            with torch.cuda.stream(comm):
-                pkg.dist.gather_results(b.z, b.S, b.status)
+        owed[i] = world > 1
 
     def fence():
+        if world > 1:
+            first = step_no[0] % nlanes     # oldest first: launch order
+            for k in range(nlanes):
+                gather((first + k) % nlanes)
         for lb, lst in lanes:               # (lazy hand-over: every lane's last launch is settled)
             lb.ctx.sync(lst.cuda_stream)
         if world > 1:
@@ -173,11 +194,13 @@ def run(args):
         step()
     fence()
     step_no[0] = 0
+    gathers[0] = 0
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t_start
+    assert world == 1 or gathers[0] == args.steps, (gathers[0], args.steps)   # one gather per timed step, all inside
     # kernel duration of the LAST timed step: HIP events the library records on the launch stream
     last_kernel_ms = lanes[(args.steps - 1) % nlanes][0].ctx.last_kernel_ms()
     if world > 1:
