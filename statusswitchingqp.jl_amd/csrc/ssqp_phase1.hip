@@ -27,7 +27,7 @@ constexpr int NT1 = 256;
 constexpr double INF = __builtin_huge_val();
 
 struct Ws {  // per-QP global workspace, all of length N1 unless noted
-    double *A1, *Y;  // M0 x N1, column-major
+    double *A1, *Y;  // M0 x N1, ROW-major (entry (r, k) at r * N1 + k): a thread per column reads and writes coalesced
     double *lo, *hi, *cost, *x, *colnorm, *range;
     int32_t *S1;
     int *nonbasic;   // 1 = nonbasic
@@ -37,6 +37,30 @@ struct Ws {  // per-QP global workspace, all of length N1 unless noted
 };
 
 __device__ __forceinline__ size_t ws_doubles(int M0, int N1) { return (size_t)2 * M0 * N1 + 6 * (size_t)N1; }
+
+// ---- diagnostic build only (-DSSQP_PHASE_PROFILE): cycles per phase of the kernel, thread 0 of every workgroup ----
+#ifdef SSQP_PHASE_PROFILE
+static __device__ unsigned long long g_p1phase[16];
+#define P1_DECL unsigned long long p1t = __builtin_amdgcn_s_memtime(); unsigned long long p1a[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define P1_STAMP(slot)                                                   \
+    do {                                                                 \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();      \
+        p1a[slot] += t_ - p1t;                                           \
+        p1t = t_;                                                        \
+    } while (0)
+#define P1_COUNT(slot) p1a[slot] += 1
+#define P1_FLUSH()                                                                                                     \
+    do {                                                                                                               \
+        if (threadIdx.x == 0)                                                                                          \
+            for (int k_ = 0; k_ < 16; ++k_)                                                                            \
+                (void)__hip_atomic_fetch_add(&g_p1phase[k_], p1a[k_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     \
+    } while (0)
+#else
+#define P1_DECL do { } while (0)
+#define P1_STAMP(slot) do { } while (0)
+#define P1_COUNT(slot) do { } while (0)
+#define P1_FLUSH() do { } while (0)
+#endif
 
 // block-wide (value, index) maximum with the FIRST maximum winning (smallest index on ties); all threads get it
 __device__ __forceinline__ void block_first_max(double &v, int &idx, double *rv, int *ri) {
@@ -160,11 +184,12 @@ struct P1Params {
     size_t wsIntStride;
 };
 
-__global__ __launch_bounds__(NT1) void ssqp_phase1_kernel(P1Params P) {
+__global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (four workgroups per CU: 1,024 QPs resident)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int prob = blockIdx.x;
     if (prob >= P.nprob) return;
     const int tid = threadIdx.x;
+    P1_DECL;
     const int N = P.N, M = P.M, J = P.J, M0 = M + J;
     const double *A = P.A + (size_t)prob * M * N;
     const double *G = P.G + (size_t)prob * J * N;
@@ -183,7 +208,8 @@ __global__ __launch_bounds__(NT1) void ssqp_phase1_kernel(P1Params P) {
     double *xb = rhs + M0;
     double *pv = xb + M0;
     double *acc = pv + M0;
-    double *redv = acc + M0;                       // 4
+    double *blo = acc + M0, *bhi = blo + M0;       // bounds of the basic variables by row
+    double *redv = bhi + M0;                       // 4
     int *basis = reinterpret_cast<int *>(redv + 4);  // M0
     int *piv = basis + M0;                         // M0
     int *redi = piv + M0;                          // 4
@@ -214,23 +240,23 @@ __global__ __launch_bounds__(NT1) void ssqp_phase1_kernel(P1Params P) {
     }
     __syncthreads();
     for (int k = tid; k < N; k += NT1) {
-        for (int r = 0; r < M; ++r) A1[(size_t)k * M0 + r] = A[(size_t)k * M + r];
-        for (int r = 0; r < J; ++r) A1[(size_t)k * M0 + M + r] = G[(size_t)k * J + r];
+        for (int r = 0; r < M; ++r) A1[(size_t)(r) * N1 + k] = A[(size_t)k * M + r];
+        for (int r = 0; r < J; ++r) A1[(size_t)(M + r) * N1 + k] = G[(size_t)k * J + r];
         lo[k] = d[k];
         hi[k] = u[k];
     }
-    for (int j = tid; j < J; j += NT1) A1[(size_t)(N + j) * M0 + M + j] = 1.0;
+    for (int j = tid; j < J; j += NT1) A1[(size_t)(M + j) * N1 + (N + j)] = 1.0;
     __syncthreads();
     for (int t = tid; t < nfree; t += NT1) {
         const int k = freeVars[t];
-        for (int r = 0; r < M0; ++r) A1[(size_t)(N + J + t) * M0 + r] = -A1[(size_t)k * M0 + r];
+        for (int r = 0; r < M0; ++r) A1[(size_t)(r) * N1 + (N + J + t)] = -A1[(size_t)(r) * N1 + k];
         lo[k] = 0.0;
     }
     for (int t = tid; t < nup; t += NT1) {
         const int k = upperOnly[t];
         lo[k] = -hi[k];
         hi[k] = INF;
-        for (int r = 0; r < M0; ++r) A1[(size_t)k * M0 + r] = -A1[(size_t)k * M0 + r];
+        for (int r = 0; r < M0; ++r) A1[(size_t)(r) * N1 + k] = -A1[(size_t)(r) * N1 + k];
     }
     for (int r = tid; r < M0; r += NT1) rhs[r] = (r < M) ? b[r] : g[r - M];
     __syncthreads();
@@ -241,7 +267,7 @@ __global__ __launch_bounds__(NT1) void ssqp_phase1_kernel(P1Params P) {
             double s = 0.0;
             for (int t = 0; t < cnt; ++t) {
                 const int k = list[t];
-                s += A1[(size_t)k * M0 + r] * lo[k];
+                s += A1[(size_t)(r) * N1 + k] * lo[k];
             }
             acc[r] = s;
         }
@@ -252,7 +278,7 @@ __global__ __launch_bounds__(NT1) void ssqp_phase1_kernel(P1Params P) {
     for (int j = tid; j < M0; j += NT1) {
         const double sgn = rhs[j] >= acc[j] ? 1.0 : -1.0;
         invB[(size_t)j * M0 + j] = sgn;
-        A1[(size_t)(N0 + j) * M0 + j] = sgn;
+        A1[(size_t)(j) * N1 + (N0 + j)] = sgn;
         xb[j] = fabs(acc[j] - rhs[j]);
         basis[j] = N0 + j;
         S1[N0 + j] = SSQP_IN;
@@ -265,7 +291,7 @@ __global__ __launch_bounds__(NT1) void ssqp_phase1_kernel(P1Params P) {
         nonbasic[k] = (k >= N0) ? 0 : 1;
         range[k] = hi[k] - lo[k];
         double s = 0.0;
-        for (int r = 0; r < M0; ++r) s += A1[(size_t)k * M0 + r] * A1[(size_t)k * M0 + r];
+        for (int r = 0; r < M0; ++r) s += A1[(size_t)(r) * N1 + k] * A1[(size_t)(r) * N1 + k];
         colnorm[k] = sqrt(s);
         x[k] = S1[k] == SSQP_UP ? hi[k] : lo[k];
     }
@@ -276,80 +302,100 @@ __global__ __launch_bounds__(NT1) void ssqp_phase1_kernel(P1Params P) {
     auto refreshY = [&]() {  // Y[:,k] = invB * A1[:,k] for the nonbasic columns
         for (int k = tid; k < N1; k += NT1) {
             if (!nonbasic[k]) continue;
-            const double *ak = A1 + (size_t)k * M0;
+            const double *ak = A1 + k;  // (entry t of column k: ak[t * N1])
             if (M0 <= MC) {
                 double av[MC];
 #pragma unroll
-                for (int t = 0; t < MC; ++t) av[t] = (t < M0) ? ak[t] : 0.0;
+                for (int t = 0; t < MC; ++t) av[t] = (t < M0) ? ak[(size_t)t * N1] : 0.0;
                 for (int r = 0; r < M0; ++r) {
                     double s = 0.0;
 #pragma unroll
                     for (int t = 0; t < MC; ++t)
                         if (t < M0) s += invB[(size_t)t * M0 + r] * av[t];
-                    Y[(size_t)k * M0 + r] = s;
+                    Y[(size_t)(r) * N1 + k] = s;
                 }
             } else {
                 for (int r = 0; r < M0; ++r) {
                     double s = 0.0;
-                    for (int t = 0; t < M0; ++t) s += invB[(size_t)t * M0 + r] * ak[t];
-                    Y[(size_t)k * M0 + r] = s;
+                    for (int t = 0; t < M0; ++t) s += invB[(size_t)t * M0 + r] * ak[(size_t)t * N1];
+                    Y[(size_t)(r) * N1 + k] = s;
                 }
             }
         }
         __syncthreads();
     };
     refreshY();
+    P1_STAMP(0);  // set-up
     int status = 1;
     long loop = 0;
     for (;;) {
         // price: signed reduced costs; the entering candidate
         loop += 1;
+        P1_COUNT(14);
         const bool bland = loop > N1;
         double best = -INF;
         int bidx = 0x7fffffff;
         if (tid < M0) acc[tid] = cost[basis[tid]];  // c[basis] (LDS: broadcast reads below)
         __syncthreads();
         for (int k = tid; k < N1; k += NT1) {
-            if (!nonbasic[k]) continue;
             double s = 0.0;
+            int sk;
+            double ck, nk;
             if (M0 <= MC) {
+                // (everything the column needs is requested at once, basic or not: one memory round trip per column)
                 double yv[MC];
+                const int nb = nonbasic[k];
+                sk = S1[k];
+                ck = cost[k];
+                nk = colnorm[k];
 #pragma unroll
-                for (int r = 0; r < MC; ++r) yv[r] = (r < M0) ? Y[(size_t)k * M0 + r] : 0.0;
+                for (int r = 0; r < MC; ++r) yv[r] = (r < M0) ? Y[(size_t)(r) * N1 + k] : 0.0;
+                if (!nb) continue;
 #pragma unroll
                 for (int r = 0; r < MC; ++r)
                     if (r < M0) s += yv[r] * acc[r];
             } else {
-                for (int r = 0; r < M0; ++r) s += Y[(size_t)k * M0 + r] * acc[r];
+                if (!nonbasic[k]) continue;
+                for (int r = 0; r < M0; ++r) s += Y[(size_t)(r) * N1 + k] * acc[r];
+                sk = S1[k];
+                ck = cost[k];
+                nk = colnorm[k];
             }
-            double hv = cost[k] - s;
-            if (S1[k] == SSQP_DN) hv = -hv;
+            double hv = ck - s;
+            if (sk == SSQP_DN) hv = -hv;
             if (hv > tol) {
-                const double v = bland ? 0.0 : hv / colnorm[k];
+                const double v = bland ? 0.0 : hv / nk;
                 if (v > best || (v == best && k < bidx)) best = v, bidx = k;  // (per thread: ascending k, first max)
             }
         }
+        P1_STAMP(1);  // pricing
         block_first_max(best, bidx, redv, redi);
+        P1_STAMP(2);  // block maximum
         if (bidx == 0x7fffffff) break;  // no improving candidate: optimal
         const int k = bidx;
-        const double *ak = A1 + (size_t)k * M0;
+        const double *ak = A1 + k;  // (entry t of column k: ak[t * N1])
         for (int r = tid; r < M0; r += NT1) {
             double s = 0.0;
-            for (int t = 0; t < M0; ++t) s += invB[(size_t)t * M0 + r] * ak[t];
+            for (int t = 0; t < M0; ++t) s += invB[(size_t)t * M0 + r] * ak[(size_t)t * N1];
             pv[r] = s;
         }
+        if (tid < M0) {  // bounds of the basic variables, for the sequential test below (one round trip instead of M0)
+            const int i = basis[tid];
+            blo[tid] = lo[i];
+            bhi[tid] = hi[i];
+        }
         __syncthreads();
+        P1_STAMP(3);  // entering column
         if (tid == 0) {  // ratio test (first minimum / first maximum over the basic rows, in row order)
             const bool fromLower = S1[k] == SSQP_DN;
             int m = 0, li = -1;
             double lr = 0.0;
             int lrow = 0, lto = SSQP_DN;
             for (int j = 0; j < M0; ++j) {
-                const int i = basis[j];
                 const bool pos = pv[j] > tol, neg = pv[j] < -tol;
                 if (!pos && !neg) continue;
                 const bool toLower = fromLower ? pos : neg;
-                const double ratio = (xb[j] - (toLower ? lo[i] : hi[i])) / pv[j];
+                const double ratio = (xb[j] - (toLower ? blo[j] : bhi[j])) / pv[j];
                 const bool better = (m == 0) || (fromLower ? (ratio < lr) : (ratio > lr));
                 if (better) lr = ratio, li = m, lrow = j, lto = toLower ? SSQP_DN : SSQP_UP;
                 ++m;
@@ -378,6 +424,7 @@ __global__ __launch_bounds__(NT1) void ssqp_phase1_kernel(P1Params P) {
             misc[1] = st;
         }
         __syncthreads();
+        P1_STAMP(4);  // ratio test
         if (misc[1] == 3) {
             status = 3;
             break;
@@ -405,8 +452,10 @@ __global__ __launch_bounds__(NT1) void ssqp_phase1_kernel(P1Params P) {
                 }
             }
             __syncthreads();
-            for (int e = tid; e < M0 * M0; e += NT1) invB[e] = A1[(size_t)basis[e / M0] * M0 + e % M0];
+            for (int e = tid; e < M0 * M0; e += NT1) invB[e] = A1[(size_t)(e % M0) * N1 + basis[e / M0]];
             __syncthreads();
+            P1_STAMP(5);  // basis sort + gather
+            P1_COUNT(15);
             if (!invert_lu(invB, Bm, piv, M0, &misc[1])) {  // lu() of the reference throws (Simplex.jl:590)
                 status = -1;
                 break;
@@ -417,7 +466,9 @@ __global__ __launch_bounds__(NT1) void ssqp_phase1_kernel(P1Params P) {
                 S1[leaving] = leaveStatus;
                 x[leaving] = leaveStatus == SSQP_DN ? lo[leaving] : hi[leaving];
             }
+            P1_STAMP(6);  // inv(lu(B))
             refreshY();
+            P1_STAMP(7);  // Y = invB A
         }
         __syncthreads();
         // xb = invB*b - Y*x[nonbasic]: the nonbasic columns at a nonzero value, ascending
@@ -425,9 +476,19 @@ __global__ __launch_bounds__(NT1) void ssqp_phase1_kernel(P1Params P) {
             const int cnt = compact_columns(N1, list, &misc[0], [&](int kk) { return nonbasic[kk] && x[kk] != 0.0; });
             for (int r = tid; r < M0; r += NT1) {
                 double a2 = 0.0;
-                for (int t = 0; t < cnt; ++t) {
-                    const int kk = list[t];
-                    a2 += Y[(size_t)kk * M0 + r] * x[kk];
+                for (int t0 = 0; t0 < cnt; t0 += 4) {  // four terms' loads in flight, summed in the host's order
+                    int kk[4];
+                    double yv[4], xv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) kk[e] = list[t0 + e < cnt ? t0 + e : t0];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        yv[e] = Y[(size_t)(r) * N1 + kk[e]];
+                        xv[e] = x[kk[e]];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (t0 + e < cnt) a2 += yv[e] * xv[e];
                 }
                 double s = 0.0;
                 for (int t = 0; t < M0; ++t) s += invB[(size_t)t * M0 + r] * rhs[t];
@@ -435,8 +496,10 @@ __global__ __launch_bounds__(NT1) void ssqp_phase1_kernel(P1Params P) {
             }
             __syncthreads();
         }
+        P1_STAMP(8);  // xb
     }
     __syncthreads();
+    P1_FLUSH();
     // ---- finish(): values of the basic variables; then initQP's mapping back (SSQP.jl:533-557)
     if (status >= 0)
         for (int j = tid; j < M0; j += NT1) x[basis[j]] = xb[j];
@@ -477,7 +540,7 @@ size_t phase1_ws_ints(int N, int M, int J) {
 }
 size_t phase1_lds_bytes(int M, int J) {
     const size_t M0 = (size_t)(M + J);
-    return (2 * M0 * M0 + 4 * M0 + 4) * 8 + (2 * M0 + 4 + 8) * 4 + 64;
+    return (2 * M0 * M0 + 6 * M0 + 4) * 8 + (2 * M0 + 4 + 8) * 4 + 64;
 }
 hipError_t launch_phase1(int nprob, int N, int M, int J, const double *A, const double *G, const double *b, const double *g,
                          const double *d, const double *u, double tol, double *x0, int32_t *S, int32_t *status, double *ws,
@@ -496,4 +559,19 @@ hipError_t launch_phase1(int nprob, int N, int M, int J, const double *A, const 
     return hipGetLastError();
 }
 
+#ifdef SSQP_PHASE_PROFILE
+int phase1_debug_phases(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(p1::g_p1phase), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        static unsigned long long zero[16];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(p1::g_p1phase), zero, sizeof(zero)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
+
 }  // namespace ssqp
+
+#ifdef SSQP_PHASE_PROFILE
+extern "C" int ssqp_debug_phase1_phases(unsigned long long *out16, int reset) { return ssqp::phase1_debug_phases(out16, reset); }
+#endif

@@ -1,0 +1,28 @@
+"""Diagnostic (GPU box): cycles per phase of the Phase-1 kernel (thread 0 of every workgroup).  Uses the
+-DSSQP_PHASE_PROFILE build (make -C statusswitchingqp.jl_amd/csrc prof); shares only, never quote its run time."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["SSQP_HIP_LIB"] = os.path.join(ROOT, "statusswitchingqp.jl_amd", "libssqp_hip_prof.so")
+sys.path.insert(0, ROOT)
+import numpy as np
+import __graft_entry__ as ge
+pkg = ge.load_package()
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
+nprob = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+cfg = pkg.CONFIGS[name]
+db, prob, x0, S0 = pkg.DeviceBatch.generated(cfg, nprob)
+lib = pkg._capi.lib()
+lib.ssqp_debug_phase1_phases.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+out = (C.c_ulonglong * 16)()
+db.phase1(); db.torch.cuda.synchronize()
+lib.ssqp_debug_phase1_phases(out, 1)
+db.phase1(); db.torch.cuda.synchronize()
+lib.ssqp_debug_phase1_phases(out, 1)
+names = ["set-up (LP assembly, first Y)", "pricing", "block maximum", "entering column invB a_k", "ratio test (thread 0)",
+         "basis sort + gather", "inv(lu(B))", "Y = invB A1", "xb = invB b - Y x"]
+tot = sum(out[:9])
+it, bc = out[14], out[15]
+print("config", name, "nprob", nprob, "simplex passes per QP %.1f, basis changes per QP %.1f, cycles per QP %.0f" % (
+    it / nprob, bc / nprob, tot / nprob))
+for i, n in enumerate(names):
+    print("%-34s %6.2f %%  %9.0f cycles per QP" % (n, 100.0 * out[i] / tot, out[i] / nprob))
