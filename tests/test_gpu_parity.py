@@ -208,7 +208,7 @@ def test_device_generator_is_bit_identical(pkg):
 
 
 def test_incremental_and_from_scratch_agree(pkg, orc):
-    """the kept-factor engine (default) and the from-scratch factorisation (SSQP_INCREMENTAL=0) take the same
+    """the kept-factor engine (default) and the from-scratch factorisation (option incremental=0) take the same
     decisions as the oracle"""
     cfg = pkg.GenConfig(160, 1, 5, 320, 1e-3, 0.06, 0.98, 0.1)
     for inc in (1, 0):
