@@ -23,14 +23,40 @@ def kkt_report(V, A, G, q, b, g, d, u, z, S, eps=1e-7):
     F = Sz == IN
     E = np.flatnonzero(G @ z - g > -eps) if J else np.zeros(0, int)     # active by residual, not by label
     C = np.vstack([A, G[E]]) if (M + len(E)) else np.zeros((0, N))
+    dn, up = Sz == DN, Sz == UP
     if C.shape[0] and F.any():
         lam = np.linalg.lstsq(C[:, F].T, -grad[F], rcond=None)[0]
     else:
         lam = np.zeros(C.shape[0])
     gamma = grad + C.T @ lam
+    if C.shape[0] and (np.linalg.matrix_rank(C[:, F]) < C.shape[0] if F.any() else True):
+        # degenerate vertex (more active rows than independent free columns): the multipliers are not unique and the
+        # least-norm ones need not be the sign-feasible ones -- the point is optimal iff SOME multipliers satisfy every
+        # condition, which is a linear feasibility problem
+        bad = ((len(E) and lam[M:].min() <= -eps) or (dn.any() and gamma[dn].min() <= -eps) or
+               (up.any() and gamma[up].max() >= eps))
+        if bad:
+            from scipy.optimize import linprog
+            t = eps / 4
+            rows, rhs = [], []
+            if F.any():
+                rows += [C[:, F].T, -C[:, F].T]
+                rhs += [-grad[F] + t, grad[F] + t]
+            if dn.any():
+                rows.append(-C[:, dn].T)
+                rhs.append(grad[dn] + t)
+            if up.any():
+                rows.append(C[:, up].T)
+                rhs.append(-grad[up] + t)
+            bounds = [(None, None)] * M + [(-t, None)] * len(E)
+            res = linprog(np.zeros(C.shape[0]), A_ub=np.vstack(rows), b_ub=np.concatenate(rhs), bounds=bounds,
+                          method="highs")
+            if res.status == 0:
+                lam = res.x
+                gamma = grad + C.T @ lam
+                rep["multipliers"] = "linear feasibility (degenerate vertex)"
     rep["stationarity_free"] = float(np.abs(gamma[F]).max()) if F.any() else 0.0
     rep["mu_min"] = float(lam[M:].min()) if len(E) else 0.0             # inequality multipliers must be >= 0
-    dn, up = Sz == DN, Sz == UP
     rep["gamma_dn_min"] = float(gamma[dn].min()) if dn.any() else 0.0   # >= 0 at lower bounds
     rep["gamma_up_max"] = float(gamma[up].max()) if up.any() else 0.0   # <= 0 at upper bounds
     rep["at_bound"] = float(max(np.abs(z[dn] - np.asarray(d)[dn]).max() if dn.any() else 0.0,
