@@ -271,6 +271,32 @@ def run(args):
                    "same_S_and_iters": bool(np.array_equal(r2["S"], res["S"]) and np.array_equal(r2["status"], res["status"])),
                    "note": "ssqp_phase1_batch_dev_f64 + the loop per step, one stream; the host C++ Phase-1 "
                            "(ssqp_phase1_batch_f64) is the alternative when M + J is large"}
+            if nlanes > 1 and world == 1:
+                # the same with the launch lanes of the timed region: Phase-1 and loop of a step on its lane's stream
+                # (each lane writes its own vertex), so one step's Phase-1 runs beside another step's loop
+                ctx.set_option("wave_qp_per_cu", qpc_lanes)
+                for lb, _ in lanes[1:]:
+                    lb.x0, lb.S0 = lb.x0.clone(), lb.S0.clone()
+
+                def e2e_steps(n):
+                    for i in range(n):
+                        lb, lst = lanes[i % nlanes]
+                        with torch.cuda.stream(lst):
+                            lb.phase1()
+                            lb.solve()
+                    for lb, lst in lanes:
+                        lb.ctx.sync(lst.cuda_stream)
+                    torch.cuda.synchronize(dev)
+                e2e_steps(nlanes)
+                ts = time.perf_counter()
+                e2e_steps(args.steps)
+                dtl = (time.perf_counter() - ts) / args.steps
+                same = True
+                for lb, _ in lanes:
+                    r3 = lb.results()
+                    same = same and bool(np.array_equal(r3["S"], res["S"]) and np.array_equal(r3["status"], res["status"]))
+                e2e["lanes"] = {"streams": nlanes, "qps": P / dtl, "ms_per_step": 1e3 * dtl, "same_S_and_iters": same}
+                ctx.set_option("wave_qp_per_cu", 4)
         except Exception as exc:   # (e.g. M + J too large for the GPU Phase-1)
             e2e = {"error": str(exc)}
     # the same problem through the workgroup kernel with the gamma pass reading EVERY column of V, as the reference's
