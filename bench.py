@@ -10,10 +10,13 @@ sharded across 8 GPUs") = 1024 QPs per GPU, cfg2-style problems (M=1, J=10, box 
 Weak scaling: every rank owns 1024 problems; the only collective is the final RCCL all-gather of
 (z, S, status), inside the timed region, issued from ONE communication stream.  Rank 0 prints ONE JSON line.
 
-Consecutive steps are independent batches; they are issued round-robin on `--streams` HIP streams (default 3, one
-library context per lane), so the drain of one launch -- QPs need 143..262 passes, the launch ends with the slowest --
-overlaps the start of the next.  `--streams 1` gives serial launches; the JSON carries both figures (`pipeline`), and
-the roofline figures always come from single launches timed by their own HIP events.
+Consecutive steps are independent batches: every launch lane owns a DISTINCT batch (own seeds, own V in HBM).  In
+mode "lanes" the steps are issued round-robin on `--streams` HIP streams (default 3, one library context per lane), so
+the drain of one launch -- QPs need 143..262 passes, the launch ends with the slowest -- overlaps the start of the
+next; in mode "serial" the same batches run one after the other on one stream.  Both are probed after warm-up and the
+faster one is the timed configuration (`--mode` forces one).  The top-level `roofline` describes the kernel build and
+launch mode `value` was timed on, with launch durations from HIP events over the timed region; `roofline_serial` keeps
+the single-launch figures.
 """
 import argparse
 import hashlib
@@ -31,11 +34,13 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # lanes per cycle = the 78.6 TFLOP/s vector-f64 figure; the SQ counters agree: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.05
 # quad-cycles per instruction for this kernel)
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0
-KERNEL_SOURCES = ["ssqp_wave.hip", "ssqp_kernels.hip", "ssqp_device.h", "ssqp_internal.h", "ssqp_api.hip"]
+KERNEL_SOURCES = ["ssqp_wave.hip", "ssqp_kernels.hip", "ssqp_device.h", "ssqp_internal.h", "ssqp_api.hip",
+                  "ssqp_phase1.hip", "ssqp_host.cpp", "../../include/ssqp_hip.h"]
 
 
 def kernel_source_hash():
-    """sha256 over the kernel sources: PMC figures under profiles/ are only quoted for the code they were taken on"""
+    """sha256 over the library's sources (csrc/Makefile: HASHED, same order): ssqp_version() of a binary built from
+    them ends in this hash, and PMC figures under profiles/ are only quoted for the code they were taken on"""
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
         with open(os.path.join(ROOT, "statusswitchingqp.jl_amd", "csrc", f), "rb") as fh:
@@ -54,6 +59,8 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--streams", type=int, default=3,
                     help="launch lanes: consecutive steps go round-robin to this many HIP streams (1: serial launches)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "lanes", "serial"],
+                    help="auto: probe both launch modes after warm-up and time the faster one")
     ap.add_argument("--skip-dense", action="store_true",
                     help="do not time the dense-formulation launches (profiling runs want one kernel variant)")
     ap.add_argument("--dense", action="store_true", help="time the dense (reference-shaped) formulation as the main run")
@@ -117,133 +124,176 @@ def run(args):
     ncpu = usable_cores()
     gen_threads = max(1, ncpu // max(1, min(world, 8)))
     t0 = time.time()
-    ctx = pkg.Context(local)
-    if args.dense:
-        ctx.set_option("dense_gamma", 1)
-    # several launch lanes on one GPU: the (normally empty) hand-over launch is issued lazily, see include/ssqp_hip.h:
-    # a lane's results are complete once its context was flushed (which the next solve on the lane does anyway), so
-    # with more than one rank the gather of a step is issued when its lane comes round again, right after that flush
-    lazy = 1 if args.streams > 1 else 0
-    ctx.set_option("lazy_handover", lazy)
-    # wavefronts per CU of the wavefront kernel: with several batches in flight two per SIMD (8 per CU) give more QPs/s;
-    # a single 1024-QP launch fills 4 per CU exactly and runs fastest with one per SIMD (include/ssqp_hip.h)
-    qpc_lanes = 8 if args.streams > 1 else 4
-    ctx.set_option("wave_qp_per_cu", qpc_lanes)
-    # V (the N*N*T part) is generated on the GPU, bit-identical to the host generator; the small arrays and the
-    # Phase-1 vertex (x0, S0) come from the host C++ (not timed: the metric is the hot path solveQP(Q,S,x0))
-    batch, prob, x0, S0 = pkg.DeviceBatch.generated(cfg, args.nprob, pkg.BASE_SEED + rank * args.nprob, ctx=ctx,
-                                                    device=local, nthreads=gen_threads)
+    # ---- launch lanes: ONE DISTINCT BATCH PER LANE (own seeds, own V in HBM, own context = workspace + work counters,
+    # own outputs).  Consecutive steps are independent batches; in "lanes" mode they are issued round-robin on the
+    # lanes' HIP streams so that the drain of one launch (QPs need 143..262 passes, a launch ends with its slowest)
+    # overlaps the start of the next; in "serial" mode the same batches are solved one after the other on one stream.
+    nlanes = max(1, args.streams)
+    main_stream = torch.cuda.current_stream(dev)
+
+    class Lane:
+        pass
+    lanes = []
+    for i in range(nlanes):
+        ln = Lane()
+        ln.ctx = pkg.Context(local)
+        if args.dense:
+            ln.ctx.set_option("dense_gamma", 1)
+        # V (the N*N*T part) is generated on the GPU, bit-identical to the host generator; the small arrays and the
+        # Phase-1 vertex (x0, S0) come from the host C++ (not timed: the metric is the hot path solveQP(Q,S,x0))
+        seed0 = pkg.BASE_SEED + (rank * nlanes + i) * args.nprob
+        ln.batch, ln.prob, ln.x0, ln.S0 = pkg.DeviceBatch.generated(cfg, args.nprob, seed0, ctx=ln.ctx, device=local,
+                                                                   nthreads=gen_threads)
+        ln.stream = main_stream if i == 0 else torch.cuda.Stream(dev)
+        ln.seed0 = seed0
+        lanes.append(ln)
     torch.cuda.synchronize(dev)
     t_setup = time.time() - t0
+    batch = lanes[0].batch
     P, N, J = batch.P, batch.N, batch.J
-    stream = torch.cuda.current_stream(dev)
-    # Launch lanes: consecutive steps are independent batches, issued round-robin on `--streams` HIP streams (one
-    # context = workspace + work counters per lane, inputs shared, outputs per lane).  A launch ends with its slowest
-    # QP (143..262 passes): with a single stream the slots of the QPs that finished early idle until then; with a few
-    # lanes the next launch's wavefronts take them.  Every step still solves all its QPs from (x0, S0).
-    nlanes = max(1, args.streams)
-    lanes = [(batch, stream)]
-    for _ in range(1, nlanes):
-        c2 = pkg.Context(local)
-        c2.set_option("lazy_handover", lazy)
-        c2.set_option("wave_qp_per_cu", qpc_lanes)
-        if args.dense:
-            c2.set_option("dense_gamma", 1)
-        lanes.append((batch.twin(c2), torch.cuda.Stream(dev)))
     comm = torch.cuda.Stream(dev) if world > 1 else None   # the ONE stream every gather is issued from
-    step_no = [0]
+    # the final gather: one pre-allocated receive buffer per lane, ONE collective per step (dist.PackedGather; the
+    # send side is the batch's packed output buffer itself)
+    for ln in lanes:
+        ln.pg = pkg.dist.PackedGather(P, N, J, dev, world) if world > 1 else None
+
+    # wavefronts per CU of the wavefront kernel: with several batches in flight two per SIMD (8 per CU) give more QPs/s;
+    # a single 1024-QP launch fills 4 per CU exactly and runs fastest with one per SIMD (include/ssqp_hip.h)
+    MODES = {"lanes": dict(lazy_handover=1, wave_qp_per_cu=8), "serial": dict(lazy_handover=0, wave_qp_per_cu=0)}
+    state = dict(mode="serial", step=0, gathers=0)
     owed = [False] * nlanes                 # lanes whose last solve has not been gathered yet
-    gathers = [0]
+
+    def set_mode(mode):
+        state["mode"] = mode
+        for ln in lanes:
+            ln.ctx.sync(ln.stream.cuda_stream)
+            for k, v in MODES[mode].items():
+                ln.ctx.set_option(k, v)
+        torch.cuda.synchronize(dev)
+
+    def lane_stream(i):
+        return lanes[i].stream if state["mode"] == "lanes" else main_stream
 
     def gather(i):
         """final gather of lane i's step (RCCL over xGMI), issued from the one communication stream in launch order;
-        the lane's next solve waits for it (it overwrites the buffers the gather reads)"""
-        b, st = lanes[i]
+        the lane's next solve waits for it (it overwrites the buffer the gather sends)"""
         if not owed[i]:
             return
-        b.ctx.flush()                       # (lazy hand-over: an owed workgroup-kernel launch goes out first)
+        ln = lanes[i]
+        ln.ctx.flush()                      # (lazy hand-over: an owed workgroup-kernel launch goes out first)
+        st = lane_stream(i)
         comm.wait_stream(st)
         with torch.cuda.stream(comm):
-            pkg.dist.gather_results(b.z, b.S, b.status)
+            ln.pg.gather(ln.batch.out)
         st.wait_stream(comm)
         owed[i] = False
-        gathers[0] += 1
+        state["gathers"] += 1
 
-    def step():
-        i = step_no[0] % nlanes
-        b, st = lanes[i]
-        step_no[0] += 1
+    def step(events=None):
+        i = state["step"] % nlanes
+        ln = lanes[i]
+        state["step"] += 1
         if world > 1:
             gather(i)                       # the step this lane ran last time round
-        with torch.cuda.stream(st):
-            b.solve()                       # in-kernel active-set loop, asynchronous on the lane's stream
+        with torch.cuda.stream(lane_stream(i)):
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            ln.batch.solve()                # in-kernel active-set loop, asynchronous on the lane's stream
+            if events is not None:
+                e1.record()
+                events.append((e0, e1))
         owed[i] = world > 1
 
     def fence():
         if world > 1:
-            first = step_no[0] % nlanes     # oldest first: launch order
+            first = state["step"] % nlanes  # oldest first: launch order
             for k in range(nlanes):
                 gather((first + k) % nlanes)
-        for lb, lst in lanes:               # (lazy hand-over: every lane's last launch is settled)
-            lb.ctx.sync(lst.cuda_stream)
+        for i, ln in enumerate(lanes):      # (lazy hand-over: every lane's last launch is settled)
+            ln.ctx.sync(lane_stream(i).cuda_stream)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(max(args.warmup, nlanes)):   # (every lane is warmed once)
-        step()
-    fence()
-    step_no[0] = 0
-    gathers[0] = 0
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t_start
-    assert world == 1 or gathers[0] == args.steps, (gathers[0], args.steps)   # one gather per timed step, all inside
-    # kernel duration of the LAST timed step: HIP events the library records on the launch stream
-    last_kernel_ms = lanes[(args.steps - 1) % nlanes][0].ctx.last_kernel_ms()
+    def timed(nsteps, events=None):
+        state["step"] = 0
+        state["gathers"] = 0
+        fence()
+        t = time.perf_counter()
+        for _ in range(nsteps):
+            step(events)
+        fence()
+        return time.perf_counter() - t
+
+    # ---- which mode?  Both are warmed and probed on a few steps; the faster one is the timed configuration (lanes do not
+    # help a workload whose QPs are all handed to a kernel that already fills the chip).  --mode forces one.
+    probe = {}
+    modes = ["serial"] if nlanes == 1 else ["lanes", "serial"]
+    if args.mode != "auto":
+        modes = [args.mode if nlanes > 1 else "serial"]
+    for m in modes:
+        set_mode(m)
+        timed(max(args.warmup, nlanes))                      # (every lane is warmed once in this mode)
+        if len(modes) > 1:
+            n = max(2, min(args.steps, 2 * nlanes))
+            probe[m] = timed(n) / n
+    mode = modes[0] if len(modes) == 1 else min(probe, key=probe.get)
+    if world > 1 and len(modes) > 1:                         # (one choice for the whole job)
+        flag = torch.tensor([1 if mode == "lanes" else 0], dtype=torch.int32, device=dev if not rehearsal else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        mode = "lanes" if int(flag.item()) == 1 else "serial"
+    set_mode(mode)
+    qpc_timed = 8 if mode == "lanes" else (8 if P > 4 * 256 else 4)
+
+    # ---- the timed region
+    alloc0 = torch.cuda.memory_stats(dev).get("allocation.all.allocated", 0)
+    events = []
+    elapsed = timed(args.steps, events)
+    alloc1 = torch.cuda.memory_stats(dev).get("allocation.all.allocated", 0)
+    assert world == 1 or state["gathers"] == args.steps, (state["gathers"], args.steps)   # one gather per timed step, all inside
+    launch_ms = [e0.elapsed_time(e1) for e0, e1 in events]   # HIP events on the stream each launch went to
+    k_ms = float(np.mean(launch_ms))
+    in_flight = float(np.sum(launch_ms)) * 1e-3 / elapsed    # launches in flight on average (lanes overlap)
+    # kernel duration of the LAST timed step: HIP events the library records around the solve kernel itself
+    last_kernel_ms = lanes[(args.steps - 1) % nlanes].ctx.last_kernel_ms()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if not rehearsal else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    res = batch.results()
-    lanes_agree = True
-    for lb, _ in lanes[1:]:                 # every lane solved the same batch: same decisions, all converged
-        r2 = lb.results()
-        lanes_agree = lanes_agree and bool(np.array_equal(r2["S"], res["S"]) and
-                                           np.array_equal(r2["status"], res["status"]))
-    ok = bool((res["status"] > 0).all()) and lanes_agree
+    used = lanes[:min(nlanes, args.steps)]
+    results = [ln.batch.results() for ln in lanes]
+    res = results[0]
+    ok = all(bool((r["status"] > 0).all()) for r in results[:len(used)])
+    distinct = nlanes == 1 or not np.array_equal(results[0]["S"], results[1]["S"])
     stats = res["stats"]
-    read_bytes = int(stats["read_bytes"].sum())     # bytes this kernel's formulation has to read (DESIGN.md)
+    # bytes this kernel's formulation has to read (DESIGN.md), per launch: mean over the lanes' batches
+    read_bytes = float(np.mean([r["stats"]["read_bytes"].sum() for r in results[:len(used)]]))
     dense_bytes = int(stats["alg_bytes"].sum())     # bytes of the reference's dense formulation (SURVEY.md 8d)
-    iters = res["status"].astype(np.int64)
+    iters = np.concatenate([r["status"].astype(np.int64) for r in results[:len(used)]])
     wave_share = float(((stats["path"] & 16) != 0).mean())
     handed_over = int(((stats["path"] & 32) != 0).sum())
+    big_wave = int(((stats["path"] & 64) != 0).sum())
+    mean_maxk = float(stats["max_k"].mean())
 
-    # a few more launches, each timed by its own HIP events, for the roofline figure
+    # ---- serial single launches of lane 0's batch, each timed by the library's own HIP events (the kernel alone)
+    ctx = lanes[0].ctx
+
     def timed_launches(n):
         ms = []
         for _ in range(n):
             batch.solve()
+            ctx.sync(main_stream.cuda_stream)
             torch.cuda.synchronize(dev)
             ms.append(ctx.last_kernel_ms())
         return ms
-    # (single launches on one stream: the kernels' own duration.  With several lanes the launches of the timed
-    #  region overlap, and a launch's begin-to-end time then contains slot-sharing with its neighbours.)
-    ctx.set_option("wave_qp_per_cu", 4)   # (single launches from here on: one wavefront per SIMD)
+    set_mode("serial")
     iso = timed_launches(4)
-    k_ms = float(np.mean(iso))
-    # the same K steps on ONE stream, for comparison with the pipelined figure
-    single = None
-    if nlanes > 1:
-        torch.cuda.synchronize(dev)
-        ts = time.perf_counter()
-        for _ in range(args.steps):
-            batch.solve()
-        torch.cuda.synchronize(dev)
-        single = (time.perf_counter() - ts) / args.steps
+    iso_ms = float(np.mean(iso))
+    res_serial = batch.results()
+    read_serial = int(res_serial["stats"]["read_bytes"].sum())
+    same_serial = bool(np.array_equal(res_serial["S"], res["S"]) and np.array_equal(res_serial["status"], res["status"]))
     # end-to-end solveQP(Q) = initQP + loop (SSQP.jl:224-234) with BOTH stages on the GPU, serial launches: Phase-1
     # kernel (bit-identical to the host stage that produced the resident vertex), then the loop.  Labelled, never
     # the headline: the metric is the hot path from a resident vertex.
@@ -269,34 +319,32 @@ def run(args):
             e2e = {"qps": P / dt, "ms_per_step": 1e3 * dt, "phase1_ms": ev[0].elapsed_time(ev[1]),
                    "loop_ms": ev[1].elapsed_time(ev[2]),
                    "same_S_and_iters": bool(np.array_equal(r2["S"], res["S"]) and np.array_equal(r2["status"], res["status"])),
-                   "note": "ssqp_phase1_batch_dev_f64 + the loop per step, one stream; the host C++ Phase-1 "
-                           "(ssqp_phase1_batch_f64) is the alternative when M + J is large"}
-            if nlanes > 1 and world == 1:
-                # the same with the launch lanes of the timed region: Phase-1 and loop of a step on its lane's stream
-                # (each lane writes its own vertex), so one step's Phase-1 runs beside another step's loop
-                ctx.set_option("wave_qp_per_cu", qpc_lanes)
-                for lb, _ in lanes[1:]:
-                    lb.x0, lb.S0 = lb.x0.clone(), lb.S0.clone()
+                   "note": "ssqp_phase1_batch_dev_f64 + the loop per step, one stream; shapes the GPU Phase-1 is slow "
+                           "on (large M + J) are routed to the host stage by the library"}
+            if nlanes > 1 and world == 1 and mode == "lanes":
+                # the same with the launch lanes: Phase-1 and loop of a step on its lane's stream, so one step's
+                # Phase-1 runs beside another step's loop
+                set_mode("lanes")
 
                 def e2e_steps(n):
                     for i in range(n):
-                        lb, lst = lanes[i % nlanes]
-                        with torch.cuda.stream(lst):
-                            lb.phase1()
-                            lb.solve()
-                    for lb, lst in lanes:
-                        lb.ctx.sync(lst.cuda_stream)
+                        ln = lanes[i % nlanes]
+                        with torch.cuda.stream(ln.stream):
+                            ln.batch.phase1()
+                            ln.batch.solve()
+                    for ln in lanes:
+                        ln.ctx.sync(ln.stream.cuda_stream)
                     torch.cuda.synchronize(dev)
                 e2e_steps(nlanes)
                 ts = time.perf_counter()
                 e2e_steps(args.steps)
                 dtl = (time.perf_counter() - ts) / args.steps
                 same = True
-                for lb, _ in lanes:
-                    r3 = lb.results()
-                    same = same and bool(np.array_equal(r3["S"], res["S"]) and np.array_equal(r3["status"], res["status"]))
+                for ln, r0 in zip(lanes, results):
+                    r3 = ln.batch.results()
+                    same = same and bool(np.array_equal(r3["S"], r0["S"]) and np.array_equal(r3["status"], r0["status"]))
                 e2e["lanes"] = {"streams": nlanes, "qps": P / dtl, "ms_per_step": 1e3 * dtl, "same_S_and_iters": same}
-                ctx.set_option("wave_qp_per_cu", 4)
+                set_mode("serial")
         except Exception as exc:   # (e.g. M + J too large for the GPU Phase-1)
             e2e = {"error": str(exc)}
     # the same problem through the workgroup kernel with the gamma pass reading EVERY column of V, as the reference's
@@ -321,73 +369,100 @@ def run(args):
                 pmc = pj
         except Exception:
             pmc = None
-    key = "dense_formulation" if args.dense else "default_formulation"
-    traffic = pmc[key].get("hbm_bytes_per_launch") if pmc and key in pmc else None
-    traffic_dense = pmc["dense_formulation"].get("hbm_bytes_per_launch") if pmc and "dense_formulation" in pmc else None
-    sq = pmc[key].get("sq") if pmc and key in pmc else None
-    traffic8 = (pmc["eight_per_cu_build"].get("hbm_bytes_per_launch")
-                if pmc and "eight_per_cu_build" in pmc and qpc_lanes == 8 and not args.dense else None)
+
+    def pmc_of(key):
+        return pmc[key] if pmc and key in pmc else {}
+    key_serial = "dense_formulation" if args.dense else "default_formulation"
+    key_timed = "eight_per_cu_build" if (qpc_timed == 8 and not args.dense) else key_serial
+    traffic = pmc_of(key_timed).get("hbm_bytes_per_launch")
+    sq = pmc_of(key_timed).get("sq")
+    traffic_serial = pmc_of(key_serial).get("hbm_bytes_per_launch")
+    sq_serial = pmc_of(key_serial).get("sq")
+    traffic_dense = pmc_of("dense_formulation").get("hbm_bytes_per_launch")
+
+    def issue_block(sqc, ms, iters_sum, what):
+        if not sqc or "SQ_INSTS_VALU" not in sqc:
+            return None
+        return {"bound": "valu-issue", "achieved": sqc["SQ_INSTS_VALU"] / (ms * 1e-3), "peak": VALU_ISSUE_PEAK,
+                "unit": "wave-instructions/s", "frac": sqc["SQ_INSTS_VALU"] / (ms * 1e-3) / VALU_ISSUE_PEAK,
+                "issue_active_frac": sqc["SQ_ACTIVE_INST_ANY"] / sqc["SQ_WAVE_CYCLES"],
+                "wait_frac": sqc["SQ_WAIT_ANY"] / sqc["SQ_WAVE_CYCLES"],
+                "valu_per_pass": sqc["SQ_INSTS_VALU"] / iters_sum, "salu_per_pass": sqc["SQ_INSTS_SALU"] / iters_sum,
+                "note": "SQ counters per launch of " + what + " from profiles/ (same source hash, separate --pmc passes) / "
+                        "the time one launch's worth of work takes here; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles "
+                        "per wave64 f64 VALU instruction"}
 
     out = None
     if rank == 0:
         qps = world * P * args.steps / elapsed
-        achieved = read_bytes / (k_ms * 1e-3) / 1e9
+        kname_wave = "ssqp_wave_kernel<%s>" % ("2, true" if qpc_timed == 8 else "1, false")
+        if wave_share > 0 and handed_over == P:
+            kname = "ssqp_wave_kernel<1, false, big factor>" if big_wave == P else "ssqp_solve_kernel (every QP handed over by %s)" % kname_wave
+        elif wave_share > 0:
+            kname = kname_wave
+        else:
+            kname = "ssqp_solve_kernel"
+        conc = max(1.0, in_flight)
+        achieved = read_bytes * conc / (k_ms * 1e-3) / 1e9
+        hot_set = qpc_timed * 256 * mean_maxk * N * 8.0
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "ssqp_wave_kernel (+ ssqp_solve_kernel for handed-over QPs)" if wave_share > 0 else "ssqp_solve_kernel",
-                "kernel_ms": k_ms, "alg_bytes_per_launch": read_bytes,
-                "achieved_from_traffic": None if traffic is None else traffic / (k_ms * 1e-3) / 1e9,
-                "frac_from_traffic": None if traffic is None else traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                # the timed region itself (launch lanes overlap, so per-launch durations do not add up): bytes of all
-                # its launches / its wall time
-                "achieved_timed_region": world * read_bytes * args.steps / elapsed / 1e9,
-                "frac_timed_region": read_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
-                "traffic_timed_region_build": traffic8,
-                "note": "achieved = bytes this formulation reads (counted in-kernel, L2/MALL hits included) / kernel time of "
-                        "ONE serial launch (four QPs per CU: bound by its dependent single-wavefront chains, see "
-                        "roofline_issue); achieved_from_traffic = PMC bytes (L2 misses: FETCH_SIZE x2 + WRITE_SIZE) / the same "
-                        "time.  *_timed_region = the bytes of all launches of the timed region / its wall time: with launch "
-                        "lanes (eight QPs per CU, overlapping launches) the same formulation moves its bytes at that rate, "
-                        "which is where HBM starts to bound it (about 6.3 TB/s are achievable).  The reference-shaped "
-                        "formulation of the same path is roofline_dense_formulation"}
-        issue = None
-        if sq:
-            issue = {"bound": "valu-issue", "achieved": sq["SQ_INSTS_VALU"] / (k_ms * 1e-3), "peak": VALU_ISSUE_PEAK,
-                     "unit": "wave-instructions/s", "frac": sq["SQ_INSTS_VALU"] / (k_ms * 1e-3) / VALU_ISSUE_PEAK,
-                     "issue_active_frac": sq["SQ_ACTIVE_INST_ANY"] / sq["SQ_WAVE_CYCLES"],
-                     "wait_frac": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
-                     "valu_per_pass": sq["SQ_INSTS_VALU"] / float(iters.sum()),
-                     "salu_per_pass": sq["SQ_INSTS_SALU"] / float(iters.sum()),
-                     "achieved_timed_region": sq["SQ_INSTS_VALU"] / (elapsed / args.steps),
-                     "frac_timed_region": sq["SQ_INSTS_VALU"] / (elapsed / args.steps) / VALU_ISSUE_PEAK,
-                     "note": "SQ counters per launch from profiles/ (same kernel source hash; serial four-per-CU launch) / "
-                             "this run's kernel time; *_timed_region: / the wall time per step of the timed region (launch "
-                             "lanes, eight per CU: same instruction stream per QP up to the parked row slot); peak = 256 "
-                             "CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 f64 VALU instruction"}
+                "kernel": kname, "mode": mode, "wave_qp_per_cu": qpc_timed,
+                "kernel_ms": k_ms, "launches_in_flight": in_flight, "alg_bytes_per_launch": read_bytes,
+                "achieved_from_traffic": None if traffic is None else traffic * conc / (k_ms * 1e-3) / 1e9,
+                "frac_from_traffic": None if traffic is None else traffic * conc / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "hot_set_in_flight_bytes": hot_set,
+                "note": "the kernel and launch mode `value` was timed on.  kernel_ms = average launch duration over the "
+                        "timed region (HIP events on the stream each launch went to); achieved = alg_bytes_per_launch x "
+                        "max(1, launches_in_flight) / kernel_ms, launches_in_flight = sum of launch durations / wall time "
+                        "(launch lanes overlap: a launch shares the chip with its neighbours, so bytes / its own duration "
+                        "would understate the rate the chip moves bytes at; with serial launches the factor is 1).  "
+                        "alg_bytes = bytes this formulation reads, counted in-kernel (L2/MALL hits included).  traffic = "
+                        "PMC bytes per launch of the same build (FETCH_SIZE x2 + WRITE_SIZE, separate passes); FETCH_SIZE "
+                        "counts L2->fabric requests, Infinity-Cache hits INCLUDED (MI355X_MICROARCH.md): with "
+                        "hot_set_in_flight_bytes (QPs in flight x mean final free set x one column) of the order of the "
+                        "256 MiB Infinity Cache, frac_from_traffic is an upper bound on the DRAM share.  About 6.3 TB/s "
+                        "are achievable.  Serial single launches: roofline_serial; the reference-shaped formulation: "
+                        "roofline_dense_formulation"}
+        issue = issue_block(sq, k_ms / conc, float(iters.sum()) / len(used), "the timed build")
+        roof_serial = {"bound": "hbm", "achieved": read_serial / (iso_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": read_serial / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_serial,
+                       "kernel_ms": iso_ms, "alg_bytes_per_launch": read_serial, "same_S_and_iters": same_serial,
+                       "qps": P / (iso_ms * 1e-3),
+                       "issue": issue_block(sq_serial, iso_ms, float(res_serial["status"].sum()), "the serial four-per-CU launch"),
+                       "note": "ONE launch at a time on one stream (library default for this batch size), kernel time by "
+                               "the library's own HIP events: bound by its dependent single-wavefront chains"}
         out = {
             "metric": "QPs/sec (batched N=512 dense portfolio QP, solveQP(Q,S,x0) to KKT)",
             "value": qps, "unit": "QPs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %d QPs/GPU, N=%d M=%d J=%d, V=X'X/T+%g*I, box [0,%g], Phase-1 vertex "
-                                   "resident in HBM" % (args.config, P, N, batch.M, J, cfg.delta, cfg.ub),
+            "config": {"workload": "%s: %d QPs/GPU per step, N=%d M=%d J=%d, V=X'X/T+%g*I, box [0,%g], Phase-1 vertex "
+                                   "resident in HBM; %d distinct batches per GPU (seeds %d + lane*%d), one per launch lane"
+                                   % (args.config, P, N, batch.M, J, cfg.delta, cfg.ub, nlanes, lanes[0].seed0, P),
                        "qps_per_gpu": P,
                        "parallelism": "one QP per wavefront (%d per CU in the timed region), batch sharded over %d GPU(s)"
-                                      % (qpc_lanes, world),
+                                      % (qpc_timed, world),
                        "formulation": "dense (reference-shaped)" if args.dense else "default (kept factor, cached products)"},
             "iters_to_kkt": {"mean": float(iters.mean()), "max": int(iters.max()), "min": int(iters.min())},
             "all_converged": ok,
-            "kernels": {"wavefront_kernel_share": wave_share, "handed_over_to_workgroup_kernel": handed_over},
-            "pipeline": {"streams": nlanes, "lanes_agree": lanes_agree,
+            "kernels": {"wavefront_kernel_share": wave_share, "handed_over": handed_over,
+                        "continued_in_big_factor_wave_kernel": big_wave, "mean_final_free_set": mean_maxk},
+            "pipeline": {"mode": mode, "streams": nlanes if mode == "lanes" else 1, "batches": nlanes,
+                         "batches_distinct": distinct, "probe_ms_per_step": {k: 1e3 * v for k, v in probe.items()},
                          "kernel_ms_last_timed_launch": last_kernel_ms,
-                         "single_stream_ms_per_step": None if single is None else 1e3 * single,
-                         "single_stream_qps": None if single is None else P / single,
-                         "wave_qp_per_cu": qpc_lanes,
-                         "note": "steps are independent batches issued round-robin on `streams` HIP streams (one "
-                                 "context per lane, shared inputs, per-lane outputs): the drain of one launch overlaps "
-                                 "the ramp-up of the next; every step solves all its QPs from (x0, S0)"},
+                         "launch_ms_min_max": [float(np.min(launch_ms)), float(np.max(launch_ms))],
+                         "note": "steps are independent batches (one distinct batch per lane, own seeds); mode lanes = "
+                                 "issued round-robin on `streams` HIP streams (one context per lane), the drain of one "
+                                 "launch overlaps the ramp-up of the next; mode serial = the same batches one after the "
+                                 "other on one stream.  Both modes are probed after warm-up and the faster one is timed; "
+                                 "every step solves all its QPs from (x0, S0)"},
+            "collective": {"gathers": state["gathers"], "per_step": 1 if world > 1 else 0,
+                           "bytes_per_rank_per_step": (lanes[0].pg.bytes if world > 1 else 0),
+                           "cuda_allocations_in_timed_region": int(alloc1 - alloc0)},
             "roofline": roof,
             "roofline_issue": issue,
+            "roofline_serial": roof_serial,
             "roofline_dense_formulation": None if dense is None else {
                 "bound": "hbm", "achieved": dense["read"] / (dense["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": dense["read"] / (dense["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -401,7 +476,7 @@ def run(args):
         }
         if not args.no_cpu and world == 1:
             res["V_host"] = batch.t["V"].cpu().numpy()
-            legs = cpu_baseline(pkg, prob, S0, x0, res, args.cpu_seconds, ncpu)
+            legs = cpu_baseline(pkg, lanes[0].prob, lanes[0].S0, lanes[0].x0, res, args.cpu_seconds, ncpu)
             out["cpu_baseline"] = legs[0]
             out["cpu_baseline_lapack"] = legs[1]
     if world > 1:

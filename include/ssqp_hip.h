@@ -121,8 +121,11 @@ const char *ssqp_last_error(const ssqp_ctx *ctx);
  *                     are then complete only after ssqp_sync(ctx, stream): do NOT consume them stream-ordered.
  *                     Default 0 (everything is queued on the caller's stream)
  *   "pin_host_buffers" 1: ssqp_solve_batch_f64 page-locks the caller's V array in place (hipHostRegister) and keeps it
- *                     registered until it is called with another array or the context is destroyed: uploads at
- *                     the full PCIe rate for hosts that solve out of the same buffers repeatedly; default 0
+ *                     registered until it is called with another array, the option is set back to 0 (that call
+ *                     unregisters) or the context is destroyed: uploads at the full PCIe rate for hosts that solve out
+ *                     of the same buffers repeatedly.  LIFETIME: the array must stay allocated, at the same address,
+ *                     for as long as it is registered -- set the option to 0 (or destroy the context) BEFORE freeing
+ *                     it; a registration is recognised by (pointer, size) only.  Default 0
  * Unknown names / out-of-range values: SSQP_ERR_ARG. */
 int ssqp_ctx_set_option(ssqp_ctx *ctx, const char *name, int value);
 int ssqp_ctx_get_option(ssqp_ctx *ctx, const char *name, int *value);
@@ -152,11 +155,21 @@ int ssqp_solve_full_f64(ssqp_ctx *ctx, int N, int M, int J, const double *V, con
 /* Host buffers, problems stored back to back (problem p at offset p*len).  Large batches go up in chunks of about
  * 256 MiB of V and every chunk is solved on one of four internal launch lanes as soon as it has landed: the call takes
  * the PCIe transfer plus one chunk's solve. */
+/* lambda (nprob x (M+J)) and gamma (nprob x N), both optional (NULL = not wanted): the Lagrange multipliers of the
+ * LAST pass of every QP with status > 0, laid out by constraint row / variable id --
+ *   lambda[r]  alphaL (SSQP.jl:351) of row r of [A;G] when the row was in the working set and kept by the rank
+ *              filter; for an active inequality the filter purged, the value KKTchk! computes for it (SSQP.jl:158-159);
+ *              0 for inactive inequalities and purged equality rows (the reference computes nothing for those)
+ *   gamma[i]   gamma (SSQP.jl:352) of bound variable i (sign as in the reference: an UP variable is optimal when
+ *              gamma <= tolG, a DN variable when gamma >= -tolG); 0 for free variables
+ * On the K == 0 exit (SSQP.jl:278-285; no multipliers exist there) gamma = V z + q, lambda = 0.  Not written for
+ * status <= 0.  The reference keeps these inside solveQP; they are exported so that north_star's "x/lambda within
+ * 1e-10" can be checked at the boundary. */
 int ssqp_solve_batch_f64(ssqp_ctx *ctx, int nprob, int N, int M, int J, const double *V,
                          const double *A, const double *G, const double *q, const double *b,
                          const double *g, const double *d, const double *u, int32_t *S,
                          const double *x0, double *z, const ssqp_settings *settings,
-                         int64_t *status, int32_t *detail, ssqp_stats *stats);
+                         int64_t *status, int32_t *detail, ssqp_stats *stats, double *lambda, double *gamma);
 
 /* A batch KEPT in HBM: upload the problem data once, solve it any number of times -- warm starts from another
  * (S, x0) (the three-argument solveQP, SSQP.jl:237), efficient-frontier sweeps that only replace q or b
@@ -184,7 +197,7 @@ int ssqp_solve_batch_multi_f64(ssqp_ctx *const *ctxs, int nctx, int nprob, int N
                                int64_t *status, int32_t *detail, ssqp_stats *stats);
 
 /* Device-resident buffers (all pointers are device pointers on ctx's GPU;
- * stats/trace may be NULL).  Asynchronous on `stream` (a hipStream_t passed
+ * stats/trace and the multiplier outputs dlambda/dgamma -- see ssqp_solve_batch_f64 -- may be NULL).  Asynchronous on `stream` (a hipStream_t passed
  * as void*; NULL = HIP's default stream); ssqp_sync waits for it.
  * trace holds ntrace records per problem. */
 int ssqp_solve_batch_dev_f64(ssqp_ctx *ctx, int nprob, int N, int M, int J, const double *dV,
@@ -192,7 +205,8 @@ int ssqp_solve_batch_dev_f64(ssqp_ctx *ctx, int nprob, int N, int M, int J, cons
                              const double *db, const double *dg, const double *dd,
                              const double *du, int32_t *dS, const double *dx0, double *dz,
                              const ssqp_settings *settings, int64_t *dstatus, int32_t *ddetail,
-                             ssqp_stats *dstats, ssqp_trace *dtrace, int ntrace, void *stream);
+                             ssqp_stats *dstats, ssqp_trace *dtrace, int ntrace, double *dlambda, double *dgamma,
+                             void *stream);
 /* The same with per-array problem strides in ELEMENTS (NULL = dense batch as above; a stride of 0 = that array is
  * shared by every problem).  Efficient-frontier style batches -- QP(P, q, L) / QP(P, mu, q) of the reference
  * (src/types.jl:303-339): one V (and A, G, d, u) for many q or b -- then read V out of L2 / Infinity Cache. */
@@ -205,7 +219,7 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *ctx, int nprob, int N, int M, int
                                      const double *du, const ssqp_batch_strides *strides, int32_t *dS,
                                      const double *dx0, double *dz, const ssqp_settings *settings,
                                      int64_t *dstatus, int32_t *ddetail, ssqp_stats *dstats,
-                                     ssqp_trace *dtrace, int ntrace, void *stream);
+                                     ssqp_trace *dtrace, int ntrace, double *dlambda, double *dgamma, void *stream);
 /* "lazy_handover" only: issues the launch the last call on ctx may still owe (waits for that call's wavefront kernel,
  * not for the stream).  A host that reuses the call's in/out buffers (S is in/out) must flush BEFORE it queues work
  * that overwrites them. */

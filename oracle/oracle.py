@@ -60,6 +60,9 @@ def lib():
         _lib.orc_solveQP_warm_batch2.restype = C.c_int
         _lib.orc_solveQP_warm_batch2.argtypes = [C.c_int] * 4 + [dp] * 8 + [ip, dp, dp, C.POINTER(Settings),
                                                                             C.POINTER(C.c_int64), ip, C.c_int, C.c_int]
+        _lib.orc_solveQP_warm_batch3.restype = C.c_int
+        _lib.orc_solveQP_warm_batch3.argtypes = [C.c_int] * 4 + [dp] * 8 + [ip, dp, dp, C.POINTER(Settings),
+                                                                            C.POINTER(C.c_int64), ip, C.c_int, C.c_int, dp, dp]
         _lib.orc_lapack_load.restype = C.c_int
         _lib.orc_lapack_load.argtypes = [C.c_char_p]
         _lib.orc_initQP_batch.restype = C.c_int
@@ -162,9 +165,10 @@ def lapack_available():
     return _lapack_state
 
 
-def solveQP_warm_batch(V, A, G, q, b, g, d, u, S, x0, settings=None, nthreads=0, lapack=False):
+def solveQP_warm_batch(V, A, G, q, b, g, d, u, S, x0, settings=None, nthreads=0, lapack=False, want_mult=False):
     """Back-to-back batch: V (P,N,N) with each V[p] symmetric (so C order == column-major),
-    A (P,N,M) = per-problem column-major M x N, G (P,N,J) likewise; vectors (P,len)."""
+    A (P,N,M) = per-problem column-major M x N, G (P,N,J) likewise; vectors (P,len).
+    want_mult: also return (lambda (P,M+J), gamma (P,N)), the multipliers of the last pass by row / variable id."""
     P, N = q.shape
     M = b.shape[1]
     J = g.shape[1]
@@ -177,9 +181,14 @@ def solveQP_warm_batch(V, A, G, q, b, g, d, u, S, x0, settings=None, nthreads=0,
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     if lapack and not lapack_available():
         raise RuntimeError("no LAPACK library to bind (scipy's OpenBLAS not found)")
-    used = lib().orc_solveQP_warm_batch2(P, N, M, J, *[_dp(a) for a in arrs], _ip(S), _dp(x0), _dp(z),
+    lam = np.zeros((P, M + J)) if want_mult else None
+    gam = np.zeros((P, N)) if want_mult else None
+    used = lib().orc_solveQP_warm_batch3(P, N, M, J, *[_dp(a) for a in arrs], _ip(S), _dp(x0), _dp(z),
                                          C.byref(settings), status.ctypes.data_as(C.POINTER(C.c_int64)),
-                                         _ip(detail), nthreads, 1 if lapack else 0)
+                                         _ip(detail), nthreads, 1 if lapack else 0,
+                                         _dp(lam) if want_mult else None, _dp(gam) if want_mult else None)
+    if want_mult:
+        return z, S, status, detail, used, lam, gam
     return z, S, status, detail, used
 
 

@@ -508,11 +508,35 @@ static int aStep(work_t *w, const double *p, double *z, int32_t *S, int K, int n
  * -1 for a numerical error (:314; also where Julia would throw, see *detail).
  * trace (may be NULL) receives up to ntrace records; *ntrace_out the count.
  */
+/* The multipliers of the LAST pass (may be NULL), laid out by row / variable id so that a caller can compare them
+ * without knowing the working set:
+ *   lambda (M+J): alphaL (:351) of every kept row; for an active inequality that the rank filter purged, the value
+ *                 KKTchk! computes for it (:158-159); 0 for inactive inequalities and purged equality rows (the
+ *                 reference computes nothing for those)
+ *   gamma (N):    gamma (:352) of the bound variables, 0 for the free ones
+ * written only on the successful exit (status > 0); on the K == 0 exit (:278-285, no multipliers exist in the
+ * reference) gamma = V z + q (what freeK! tests) and lambda = 0. */
+int64_t orc_solveQP_warm_ex(int N, int M, int J, const double *V, const double *A, const double *G,
+                            const double *q, const double *b, const double *g, const double *d,
+                            const double *u, int32_t *S, const double *x0, double *z,
+                            const orc_settings *st, int32_t *detail, orc_trace *trace, int ntrace,
+                            int *ntrace_out, double *lambda_out, double *gamma_out);
+
 int64_t orc_solveQP_warm(int N, int M, int J, const double *V, const double *A, const double *G,
                          const double *q, const double *b, const double *g, const double *d,
                          const double *u, int32_t *S, const double *x0, double *z,
                          const orc_settings *st, int32_t *detail, orc_trace *trace, int ntrace,
                          int *ntrace_out)
+{
+    return orc_solveQP_warm_ex(N, M, J, V, A, G, q, b, g, d, u, S, x0, z, st, detail, trace, ntrace, ntrace_out,
+                               NULL, NULL);
+}
+
+int64_t orc_solveQP_warm_ex(int N, int M, int J, const double *V, const double *A, const double *G,
+                            const double *q, const double *b, const double *g, const double *d,
+                            const double *u, int32_t *S, const double *x0, double *z,
+                            const orc_settings *st, int32_t *detail, orc_trace *trace, int ntrace,
+                            int *ntrace_out, double *lambda_out, double *gamma_out)
 {
     const int maxIter = st->maxIter;
     const double tol = st->tol, tolG = st->tolG;
@@ -536,7 +560,12 @@ int64_t orc_solveQP_warm(int N, int M, int J, const double *V, const double *A, 
             int s = freeK(S, z, V, q, N, tol, w->pN, w->S0);
             if (trace && nt < ntrace) trace[nt] = (orc_trace){0, 0, s > 0 ? 3 : 0, 0};
             nt++;
-            if (s > 0) { ret = iter; break; }
+            if (s > 0) {
+                if (lambda_out) for (int r = 0; r < M + J; ++r) lambda_out[r] = 0.0;
+                if (gamma_out) for (int j = 0; j < N; ++j) gamma_out[j] = w->pN[j];
+                ret = iter;
+                break;
+            }
             continue;
         }
         int JE = 0, nOg = 0;
@@ -757,6 +786,17 @@ int64_t orc_solveQP_warm(int N, int M, int J, const double *V, const double *A, 
             if (S[j] == ST_UP && t > tolG) Li[nL++] = (event_t){ST_UP, ST_IN, j + 1, -t};
             else if (S[j] == ST_DN && t < -tolG) Li[nL++] = (event_t){ST_DN, ST_IN, j + 1, t};
         }
+        if (lambda_out) {
+            for (int r = 0; r < M + J; ++r) lambda_out[r] = 0.0;
+            for (int r = 0; r < W; ++r) { /* kept rows: position r is row ra[r] of [A; G[Eg,:]] */
+                int row = (W == W0) ? r : w->ra[r];
+                lambda_out[row < M ? row : M + w->iEg[row - M]] = w->alphaL[r];
+            }
+        }
+        if (gamma_out) {
+            for (int j = 0; j < N; ++j) gamma_out[j] = 0.0;
+            for (int k = 0; k < R; ++k) gamma_out[w->iB[k]] = w->gamma[k];
+        }
         if (JE > 0) { /* :150-172 */
             for (int j = 0; j < JE; ++j) {
                 /* position of active inequality j among the kept rows */
@@ -777,6 +817,7 @@ int64_t orc_solveQP_warm(int N, int M, int J, const double *V, const double *A, 
                 } else {
                     Lda = w->alphaL[pos];
                 }
+                if (lambda_out) lambda_out[M + w->iEg[j]] = Lda;
                 if (Lda < -tolG) Li[nL++] = (event_t){ST_EO, ST_OE, w->iEg[j] + 1, Lda};
             }
         }
@@ -1106,12 +1147,28 @@ int orc_solveQP_warm_batch(int nprob, int N, int M, int J, const double *V, cons
     return orc_solveQP_warm_batch2(nprob, N, M, J, V, A, G, q, b, g, d, u, S, x0, z, st, status, detail, nthreads, 0);
 }
 
+int orc_solveQP_warm_batch3(int nprob, int N, int M, int J, const double *V, const double *A,
+                            const double *G, const double *q, const double *b, const double *g,
+                            const double *d, const double *u, int32_t *S, const double *x0,
+                            double *z, const orc_settings *st, int64_t *status, int32_t *detail,
+                            int nthreads, int lapack, double *lambda, double *gamma);
 /* lapack != 0: the dense arithmetic by LAPACK/BLAS (orc_lapack_load must have succeeded) */
 int orc_solveQP_warm_batch2(int nprob, int N, int M, int J, const double *V, const double *A,
                             const double *G, const double *q, const double *b, const double *g,
                             const double *d, const double *u, int32_t *S, const double *x0,
                             double *z, const orc_settings *st, int64_t *status, int32_t *detail,
                             int nthreads, int lapack)
+{
+    return orc_solveQP_warm_batch3(nprob, N, M, J, V, A, G, q, b, g, d, u, S, x0, z, st, status, detail, nthreads,
+                                   lapack, NULL, NULL);
+}
+
+/* lambda (nprob x (M+J)) and gamma (nprob x N) may be NULL: the multipliers of the last pass (orc_solveQP_warm_ex) */
+int orc_solveQP_warm_batch3(int nprob, int N, int M, int J, const double *V, const double *A,
+                            const double *G, const double *q, const double *b, const double *g,
+                            const double *d, const double *u, int32_t *S, const double *x0,
+                            double *z, const orc_settings *st, int64_t *status, int32_t *detail,
+                            int nthreads, int lapack, double *lambda, double *gamma)
 {
     int used = 1;
     if (lapack && !LP.h) return -1;
@@ -1124,10 +1181,10 @@ int orc_solveQP_warm_batch2(int nprob, int N, int M, int J, const double *V, con
         size_t P = (size_t)p;
         int32_t det = 0;
         t_lapack = lapack;
-        status[p] = orc_solveQP_warm(N, M, J, V + P * N * N, A + P * M * N, G + P * J * N,
-                                     q + P * N, b + P * M, g + P * J, d + P * N, u + P * N,
-                                     S + P * (N + J), x0 + P * N, z + P * N, st, &det, NULL, 0,
-                                     NULL);
+        status[p] = orc_solveQP_warm_ex(N, M, J, V + P * N * N, A + P * M * N, G + P * J * N,
+                                        q + P * N, b + P * M, g + P * J, d + P * N, u + P * N,
+                                        S + P * (N + J), x0 + P * N, z + P * N, st, &det, NULL, 0,
+                                        NULL, lambda ? lambda + P * (M + J) : NULL, gamma ? gamma + P * N : NULL);
         if (detail) detail[p] = det;
         t_lapack = 0;
     }

@@ -63,7 +63,7 @@ SIGNATURES = {
     "ssqp_solve_full_f64": (C.c_int, [_vp] + [C.c_int] * 3 + [_vp] * 8 + [C.c_int, _vp, _vp, C.POINTER(CSettings),
                                                                           C.POINTER(CSettings), _lp, _ip]),
     "ssqp_solve_batch_f64": (C.c_int, [_vp] + [C.c_int] * 4 + [_vp] * 8 + [_vp, _vp, _vp, C.POINTER(CSettings),
-                                                                          _vp, _vp, _vp]),
+                                                                          _vp, _vp, _vp, _vp, _vp]),
     "ssqp_problem_upload": (C.c_int, [_vp] + [C.c_int] * 4 + [_vp] * 8 + [C.POINTER(_vp)]),
     "ssqp_problem_set_vector": (C.c_int, [_vp, C.c_int, _vp]),
     "ssqp_problem_solve": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(CSettings), _vp, _vp, _vp]),
@@ -71,9 +71,9 @@ SIGNATURES = {
     "ssqp_solve_batch_multi_f64": (C.c_int, [C.POINTER(_vp), C.c_int] + [C.c_int] * 4 + [_vp] * 8 +
                                    [_vp, _vp, _vp, C.POINTER(CSettings), _vp, _vp, _vp]),
     "ssqp_solve_batch_dev_f64": (C.c_int, [_vp] + [C.c_int] * 4 + [_vp] * 8 + [_vp, _vp, _vp, C.POINTER(CSettings),
-                                                                              _vp, _vp, _vp, _vp, C.c_int, _vp]),
+                                                                              _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "ssqp_solve_batch_strided_dev_f64": (C.c_int, [_vp] + [C.c_int] * 4 + [_vp] * 8 + [C.POINTER(CStrides)] +
-                                         [_vp, _vp, _vp, C.POINTER(CSettings), _vp, _vp, _vp, _vp, C.c_int, _vp]),
+                                         [_vp, _vp, _vp, C.POINTER(CSettings), _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "ssqp_sync": (C.c_int, [_vp, _vp]),
     "ssqp_flush": (C.c_int, [_vp]),
     "ssqp_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),

@@ -40,7 +40,7 @@ struct ssqp_ctx {
     // grow-only device workspaces
     DevBuf Ct, rhs, queue, gscratch, fbList, fbIter, wscratch, p1ws, p1wsInt;
     // staging buffers of the host-pointer entry points
-    DevBuf hV, hA, hG, hq, hb, hg, hd, hu, hS, hx0, hz, hstatus, hdetail, hstats;
+    DevBuf hV, hA, hG, hq, hb, hg, hd, hu, hS, hx0, hz, hstatus, hdetail, hstats, hlam, hgam;
     // lazy hand-over: the launch the wavefront kernel may still owe (its hand-over count lands in pinned memory)
     unsigned int *hostCount = nullptr;   // pinned
     hipEvent_t evCount = nullptr;
@@ -49,6 +49,8 @@ struct ssqp_ctx {
     int pendGrid = 0, pendWg = 0;
     size_t pendLds = 0;
     hipStream_t pendStream = nullptr;
+    hipStream_t owedStream = nullptr;    // stream an owed hand-over launch went out on (ordered before the next call's resets)
+    hipEvent_t evOwed = nullptr;
     // launch lanes of the host-buffer batch entry: child contexts (own stream, workspaces, work counters) so that
     // the solve of one chunk overlaps the upload of the next and the solves of neighbouring chunks
     std::vector<ssqp_ctx *> lanes;
@@ -141,12 +143,14 @@ int ssqp_ctx_destroy(ssqp_ctx *c) {
     c->hostCount = nullptr;
     if (c->evCount) (void)hipEventDestroy(c->evCount);
     c->evCount = nullptr;
+    if (c->evOwed) (void)hipEventDestroy(c->evOwed);
+    c->evOwed = nullptr;
     for (ssqp_ctx *l : c->lanes) (void)ssqp_ctx_destroy(l);
     c->lanes.clear();
     for (hipEvent_t &e : c->evCopy)
         if (e) (void)hipEventDestroy(e), e = nullptr;
     for (DevBuf *b : {&c->Ct, &c->rhs, &c->queue, &c->gscratch, &c->fbList, &c->fbIter, &c->wscratch, &c->p1ws, &c->p1wsInt, &c->hV, &c->hA, &c->hG, &c->hq, &c->hb, &c->hg,
-                      &c->hd, &c->hu, &c->hS, &c->hx0, &c->hz, &c->hstatus, &c->hdetail, &c->hstats})
+                      &c->hd, &c->hu, &c->hS, &c->hx0, &c->hz, &c->hstatus, &c->hdetail, &c->hstats, &c->hlam, &c->hgam})
         release(*b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -183,6 +187,13 @@ int ssqp_ctx_set_option(ssqp_ctx *c, const char *name, int value) {
         return SSQP_ERR_ARG;
     }
     *slot = value;
+    if (slot == &c->optPinHost && value == 0 && c->pinnedPtr) {  // the registration ends with the option
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        if (hipHostUnregister(const_cast<void *>(c->pinnedPtr)) != hipSuccess) (void)hipGetLastError();
+        c->pinnedPtr = nullptr;
+        c->pinnedBytes = 0;
+    }
     return SSQP_OK;
 }
 int ssqp_ctx_get_option(ssqp_ctx *c, const char *name, int *value) {
@@ -202,6 +213,20 @@ static int finish_pending(ssqp_ctx *c) {
     if (!hip_ok(c, ssqp::launch_solve(c->pendP, c->pendGrid, c->pendLds, c->pendWg, c->pendStream), "solve launch"))
         return SSQP_ERR_HIP;
     if (!hip_ok(c, hipEventRecord(c->ev1, c->pendStream), "hipEventRecord")) return SSQP_ERR_HIP;
+    c->owedStream = c->pendStream;
+    return SSQP_OK;
+}
+
+// The owed launch went out on the stream of the call that owed it.  A later call on ANOTHER stream resets the shared
+// work counters and (through its caller) the in/out buffers: it has to queue behind that launch.
+static int order_after_owed(ssqp_ctx *c, hipStream_t s) {
+    if (!c->owedStream) return SSQP_OK;
+    hipStream_t o = c->owedStream;
+    c->owedStream = nullptr;
+    if (o == s) return SSQP_OK;
+    if (!c->evOwed && !hip_ok(c, hipEventCreateWithFlags(&c->evOwed, hipEventDisableTiming), "hipEventCreate")) return SSQP_ERR_HIP;
+    if (!hip_ok(c, hipEventRecord(c->evOwed, o), "hipEventRecord") || !hip_ok(c, hipStreamWaitEvent(s, c->evOwed, 0), "hipStreamWaitEvent"))
+        return SSQP_ERR_HIP;
     return SSQP_OK;
 }
 
@@ -239,7 +264,7 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
                                      const double *dd, const double *du, const ssqp_batch_strides *strides,
                                      int32_t *dS, const double *dx0, double *dz, const ssqp_settings *settings,
                                      int64_t *dstatus, int32_t *ddetail, ssqp_stats *dstats, ssqp_trace *dtrace,
-                                     int ntrace, void *stream) {
+                                     int ntrace, double *dlambda, double *dgamma, void *stream) {
     ssqp_batch_strides st0;
     st0.V = (size_t)N * N; st0.A = (size_t)M * N; st0.G = (size_t)J * N; st0.q = N; st0.b = M; st0.g = J; st0.d = N; st0.u = N;
     const ssqp_batch_strides *sd = strides ? strides : &st0;
@@ -257,7 +282,8 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
     if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return SSQP_ERR_HIP;
     hipStream_t s = (hipStream_t)stream;  // NULL is HIP's default stream (what torch uses unless told otherwise)
     {
-        const int rcp = finish_pending(c);  // (lazy hand-over of the previous call on this context)
+        int rcp = finish_pending(c);  // (lazy hand-over of the previous call on this context)
+        if (rcp == SSQP_OK) rcp = order_after_owed(c, s);
         if (rcp != SSQP_OK) return rcp;
     }
 
@@ -329,6 +355,8 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
     P.S = dS; P.z = dz; P.status = dstatus; P.detail = ddetail; P.stats = dstats;
     P.trace = (ntrace > 0) ? dtrace : nullptr;
     P.ntrace = (dtrace && ntrace > 0) ? ntrace : 0;
+    P.lamOut = (MJ > 0) ? dlambda : nullptr;
+    P.gamOut = dgamma;
     P.maxIter = st->maxIter; P.tol = st->tol; P.tolG = st->tolG;
     P.queue = (unsigned int *)c->queue.p;
     P.gscratch = (double *)c->gscratch.p;
@@ -394,9 +422,10 @@ int ssqp_solve_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const 
                              const double *dG, const double *dq, const double *db, const double *dg,
                              const double *dd, const double *du, int32_t *dS, const double *dx0, double *dz,
                              const ssqp_settings *settings, int64_t *dstatus, int32_t *ddetail,
-                             ssqp_stats *dstats, ssqp_trace *dtrace, int ntrace, void *stream) {
+                             ssqp_stats *dstats, ssqp_trace *dtrace, int ntrace, double *dlambda, double *dgamma,
+                             void *stream) {
     return ssqp_solve_batch_strided_dev_f64(c, nprob, N, M, J, dV, dA, dG, dq, db, dg, dd, du, nullptr, dS, dx0, dz,
-                                            settings, dstatus, ddetail, dstats, dtrace, ntrace, stream);
+                                            settings, dstatus, ddetail, dstats, dtrace, ntrace, dlambda, dgamma, stream);
 }
 
 int ssqp_generate_V_dev(ssqp_ctx *c, const ssqp_gen_cfg *cfg, uint64_t seed0, int nprob, double *dV, void *stream) {
@@ -427,7 +456,7 @@ static ssqp_ctx *lane_of(ssqp_ctx *c, int i) {
 int ssqp_solve_batch_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const double *V, const double *A,
                          const double *G, const double *q, const double *b, const double *g, const double *d,
                          const double *u, int32_t *S, const double *x0, double *z, const ssqp_settings *settings,
-                         int64_t *status, int32_t *detail, ssqp_stats *stats) {
+                         int64_t *status, int32_t *detail, ssqp_stats *stats, double *lambda, double *gamma) {
     int rc = check_dims(c, nprob, N, M, J);
     if (rc != SSQP_OK) return rc;
     if (!V || !q || !d || !u || !S || !x0 || !z || !status || (M > 0 && (!A || !b)) || (J > 0 && (!G || !g))) {
@@ -446,6 +475,10 @@ int ssqp_solve_batch_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const doub
     if (!ensure(c, c->hz, P * n * 8) || !ensure(c, c->hstatus, P * 8) || !ensure(c, c->hdetail, P * 4) ||
         !ensure(c, c->hstats, P * sizeof(ssqp_stats)))
         return SSQP_ERR_ALLOC;
+    if ((lambda && !ensure(c, c->hlam, P * (m + j) * 8)) || (gamma && !ensure(c, c->hgam, P * n * 8))) return SSQP_ERR_ALLOC;
+    // (multipliers are written for status > 0 only: the buffers start from zero)
+    if (lambda && !hip_ok(c, hipMemsetAsync(c->hlam.p, 0, P * (m + j) * 8 + 8, c->stream), "hipMemsetAsync")) return SSQP_ERR_HIP;
+    if (gamma && !hip_ok(c, hipMemsetAsync(c->hgam.p, 0, P * n * 8, c->stream), "hipMemsetAsync")) return SSQP_ERR_HIP;
     // The upload of V (N*N*8 bytes per QP over PCIe) dwarfs the solve: the batch goes up in chunks, and every chunk is
     // solved on one of four launch lanes (child contexts) as soon as it has landed -- the solves run behind the
     // upload of the following chunks and beside each other, so the call takes the transfer plus one chunk's solve.
@@ -496,10 +529,16 @@ int ssqp_solve_batch_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const doub
                                       (const double *)at(c->hu, n * 8), (int32_t *)at(c->hS, (n + j) * 4),
                                       (const double *)at(c->hx0, n * 8), (double *)at(c->hz, n * 8), settings,
                                       (int64_t *)at(c->hstatus, 8), (int32_t *)at(c->hdetail, 4),
-                                      (ssqp_stats *)at(c->hstats, sizeof(ssqp_stats)), nullptr, 0, ls);
+                                      (ssqp_stats *)at(c->hstats, sizeof(ssqp_stats)), nullptr, 0,
+                                      lambda ? (double *)at(c->hlam, (m + j) * 8) : nullptr,
+                                      gamma ? (double *)at(c->hgam, n * 8) : nullptr, ls);
         if (rc != SSQP_OK) {
             if (l != c) c->err = l->err;
             return rc;
+        }
+        if (l == c) {  // "lazy_handover" on the caller's context: the owed launch goes out before the results are read
+            rc = finish_pending(c);
+            if (rc != SSQP_OK) return rc;
         }
     }
     for (int i = 0; i < nlane && nlane > 1; ++i)
@@ -519,6 +558,10 @@ int ssqp_solve_batch_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const doub
         return SSQP_ERR_HIP;
     if (stats && !hip_ok(c, hipMemcpyAsync(stats, c->hstats.p, P * sizeof(ssqp_stats), hipMemcpyDeviceToHost,
                                            c->stream), "D2H"))
+        return SSQP_ERR_HIP;
+    if (lambda && (m + j) > 0 && !hip_ok(c, hipMemcpyAsync(lambda, c->hlam.p, P * (m + j) * 8, hipMemcpyDeviceToHost, c->stream), "D2H"))
+        return SSQP_ERR_HIP;
+    if (gamma && !hip_ok(c, hipMemcpyAsync(gamma, c->hgam.p, P * n * 8, hipMemcpyDeviceToHost, c->stream), "D2H"))
         return SSQP_ERR_HIP;
     if (!hip_ok(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return SSQP_ERR_HIP;
     return SSQP_OK;
@@ -599,7 +642,8 @@ int ssqp_problem_solve(ssqp_problem *p, int32_t *S, const double *x0, double *z,
                                       (const double *)p->g.p, (const double *)p->d.p, (const double *)p->u.p,
                                       (int32_t *)p->S.p, (const double *)p->x0.p, (double *)p->z.p, settings,
                                       (int64_t *)p->status.p, (int32_t *)p->detail.p, (ssqp_stats *)p->stats.p, nullptr, 0,
-                                      c->stream);
+                                      nullptr, nullptr, c->stream);
+    if (rc == SSQP_OK) rc = finish_pending(c);  // ("lazy_handover": the owed launch goes out before the results are read)
     if (rc != SSQP_OK) return rc;
     if (!hip_ok(c, hipMemcpyAsync(z, p->z.p, P * n * 8, hipMemcpyDeviceToHost, c->stream), "D2H") ||
         !hip_ok(c, hipMemcpyAsync(S, p->S.p, P * (n + j) * 4, hipMemcpyDeviceToHost, c->stream), "D2H") ||
@@ -629,7 +673,7 @@ int ssqp_phase1_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const
         c->err = "only rule = :Dantzig is implemented for Phase-1";
         return SSQP_ERR_UNSUPPORTED;
     }
-    if (ssqp::phase1_lds_bytes(M, J) > (size_t)ssqp::LDS_BYTES) {
+    if (M + J > ssqp::NT || ssqp::phase1_lds_bytes(M, J) > (size_t)ssqp::LDS_BYTES) {  // (one thread per basic row)
         c->err = "M + J too large for the GPU Phase-1 (the basis inverse does not fit in LDS): use ssqp_phase1_batch_f64";
         return SSQP_ERR_UNSUPPORTED;
     }
@@ -665,7 +709,7 @@ int ssqp_solve_batch_multi_f64(ssqp_ctx *const *ctxs, int nctx, int nprob, int N
                                                   G ? G + o * j * n : nullptr, q + o * n, b ? b + o * m : nullptr,
                                                   g ? g + o * j : nullptr, d + o * n, u + o * n, S + o * (n + j),
                                                   x0 + o * n, z + o * n, settings, status + o,
-                                                  detail ? detail + o : nullptr, stats ? stats + o : nullptr);
+                                                  detail ? detail + o : nullptr, stats ? stats + o : nullptr, nullptr, nullptr);
         });
     }
     for (std::thread &t : th) t.join();
@@ -677,7 +721,7 @@ int ssqp_solve_batch_multi_f64(ssqp_ctx *const *ctxs, int nctx, int nprob, int N
 int ssqp_solve_f64(ssqp_ctx *c, int N, int M, int J, const double *V, const double *A, const double *G,
                    const double *q, const double *b, const double *g, const double *d, const double *u, int32_t *S,
                    const double *x0, double *z, const ssqp_settings *settings, int64_t *status, int32_t *detail) {
-    return ssqp_solve_batch_f64(c, 1, N, M, J, V, A, G, q, b, g, d, u, S, x0, z, settings, status, detail, nullptr);
+    return ssqp_solve_batch_f64(c, 1, N, M, J, V, A, G, q, b, g, d, u, S, x0, z, settings, status, detail, nullptr, nullptr, nullptr);
 }
 
 int ssqp_solve_full_f64(ssqp_ctx *c, int N, int M, int J, const double *V, const double *A, const double *G,

@@ -431,7 +431,11 @@ int phase1_one(int N, int M, int J, const double *A, const double *G, const doub
 
 extern "C" {
 
-const char *ssqp_version(void) { return "ssqp_hip 0.1 (gfx950)"; }
+#ifndef SSQP_SRC_HASH
+#define SSQP_SRC_HASH "unknown"
+#endif
+// "ssqp_hip <version> (gfx950) src=<sha256 of the sources this binary was built from>" (csrc/Makefile: HASHED)
+const char *ssqp_version(void) { return "ssqp_hip 0.3 (gfx950) src=" SSQP_SRC_HASH; }
 
 void ssqp_default_settings(ssqp_settings *s) {
     if (!s) return;

@@ -34,6 +34,9 @@ struct SolveParams {
     ssqp_stats *stats;
     ssqp_trace *trace;
     int ntrace;
+    // multipliers of the last pass (SSQP.jl:351-352, 149-171), by row / variable id; either may be null
+    double *lamOut;   // nprob x MJ
+    double *gamOut;   // nprob x N
     int maxIter;
     double tol, tolG;
     unsigned int *queue;     // work counter, zeroed before the launch
@@ -128,6 +131,21 @@ inline size_t global_arena_doubles(int N, int M, int J) {
     const size_t eng = (size_t)NW * N + 64 + 13 * rcg + rcg * (rcg + 1) / 2 + 64;
     if (f < eng) f = eng;
     return (x > f ? x : f) + 64;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the kernel (per device), not to a launch: two host threads that
+// set different sizes before their launches would race.  It is set ONCE per kernel and device, to the whole LDS; the
+// size a launch asks for is what decides the residency.  `doneMask`: one static word per kernel, bit = device.
+inline hipError_t allow_full_lds(const void *fn, unsigned long long *doneMask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(doneMask, __ATOMIC_ACQUIRE) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return e;
+    __atomic_fetch_or(doneMask, bit, __ATOMIC_RELEASE);
+    return hipSuccess;
 }
 
 void launch_prep(int nct, int nrhs, int N, int M, int J, const double *A, const double *G, const double *b,

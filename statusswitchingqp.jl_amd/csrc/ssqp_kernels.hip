@@ -1698,6 +1698,7 @@ struct ProbCtx {
     const double *__restrict__ uhi;
     ssqp_trace *trace;
     int ntrace;
+    double *lamOut, *gamOut;  // this problem's multiplier outputs (null: not requested)
     int arenaCap;
     bool dense;       // read zero-weight columns too (roofline measurement of the dense formulation)
     double *garena;
@@ -2671,6 +2672,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
                 __syncthreads();
             }
             if (tid == 0 && Lda < -tolG) ev = keymin(ev, KeyMin{Lda, N + (int)L.rowsE[wrow] - M});
+            if (tid == 0 && posk < 0 && C.lamOut) C.lamOut[L.rowsE[wrow]] = Lda;  // (a purged row: as KKTchk! computes it)
         }
     }
     ev = block_keymin(ev, L);
@@ -2691,7 +2693,39 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         __syncthreads();
         return ACT_CONTINUE;
     }
-    // ---- optimal: polishSz!  SSQP.jl:10-32 ----
+    // ---- optimal: the multipliers of this pass leave the kernel when asked for (alphaL SSQP.jl:351, gamma :352)
+    if (C.lamOut) {
+        for (int r = tid; r < MJ; r += NT) {
+            int posA = -1;  // position among the active rows
+            for (int w = 0; w < W0; ++w)
+                if (L.rowsE[w] == r) posA = w;
+            int posk = -1;  // ... among the kept rows
+            if (posA >= 0) {
+                if (W == W0) posk = posA;
+                else
+                    for (int w = 0; w < W; ++w)
+                        if (L.ra[w] == posA) posk = w;
+            }
+            if (posk >= 0) C.lamOut[r] = L.aL[posk];
+            else if (posA < 0 || r < M) C.lamOut[r] = 0.0;  // inactive, or a purged equality row (no value in the reference)
+            // (a purged active inequality keeps the value written above)
+        }
+    }
+    if (C.gamOut) {
+        for (int i = tid; i < N; i += NT) {
+            double gmm = 0.0;
+            if (L.pos[i] < 0) {
+                gmm = L.gam[i];
+                if (VEC == 1) {
+                    double s3 = 0.0;
+                    for (int w = 0; w < W; ++w) s3 = fma(Ct[(size_t)L.rowsE[L.ra[w]] * N + i], L.aL[w], s3);
+                    gmm = (gmm + q[i]) + s3;
+                }
+            }
+            C.gamOut[i] = gmm;
+        }
+    }
+    // ---- polishSz!  SSQP.jl:10-32 ----
     PHASE(C, 11);
     for (int i = tid; i < N; i += NT) {
         const int s = L.S[i];
@@ -2737,6 +2771,8 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
     C.uhi = P.u + (size_t)prob * P.su;
     C.trace = P.trace ? P.trace + (size_t)prob * P.ntrace : nullptr;
     C.ntrace = P.ntrace;
+    C.lamOut = P.lamOut ? P.lamOut + (size_t)prob * P.MJ : nullptr;
+    C.gamOut = P.gamOut ? P.gamOut + (size_t)prob * N : nullptr;
     C.arenaCap = P.arenaCap;
     C.dense = P.denseGamma != 0;
     C.garena = garena;
@@ -2834,6 +2870,11 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
             }
             if (done) {
                 if (trace && tid == 0) *trace = ssqp_trace{0, 0, 3, 0};
+                // (no multipliers exist on this exit of the reference: gamma = V z + q, what freeK! tested; lambda = 0)
+                if (C.lamOut)
+                    for (int r = tid; r < P.MJ; r += NT) C.lamOut[r] = 0.0;
+                if (C.gamOut)
+                    for (int i = tid; i < N; i += NT) C.gamOut[i] = L.gam[i] + C.q[i];
                 C.ret = C.iter;  // SSQP.jl:281 (no polishSz! on this exit)
                 break;
             }
@@ -3114,8 +3155,8 @@ hipError_t launch_genV(int nprob, int N, int T, double delta, unsigned long long
 
 template <int VEC, int WPS>
 static hipError_t launch_one(const SolveParams &P, int grid, size_t ldsBytes, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ssqp_solve_kernel<VEC, WPS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    static unsigned long long ldsSet = 0ull;  // (one per instantiation)
+    hipError_t e = allow_full_lds(reinterpret_cast<const void *>(&ssqp_solve_kernel<VEC, WPS>), &ldsSet);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((ssqp_solve_kernel<VEC, WPS>), dim3(grid), dim3(NT), ldsBytes, stream, P);
     return hipGetLastError();

@@ -331,6 +331,13 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
     for (;;) {
         // price: signed reduced costs; the entering candidate
         loop += 1;
+        // The reference's loop has no limit (Simplex.jl:486); Bland's rule ends it after N1 passes on any finite LP,
+        // but a workgroup that never leaves hangs the stream for good: an LP still pivoting after 64 N1 + 1024 passes
+        // (NaN-poisoned or cycling in floating point) is given up as a numerical error (status -1)
+        if (loop > 64l * N1 + 1024) {
+            status = -1;
+            break;
+        }
         P1_COUNT(14);
         const bool bland = loop > N1;
         double best = -INF;
@@ -552,8 +559,8 @@ hipError_t launch_phase1(int nprob, int N, int M, int J, const double *A, const 
     P.x0 = x0; P.S = S; P.status = status;
     P.ws = ws; P.wsStride = wsStride; P.wsInt = wsInt; P.wsIntStride = wsIntStride;
     const size_t lds = phase1_lds_bytes(M, J);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&p1::ssqp_phase1_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static unsigned long long ldsSet = 0ull;
+    hipError_t e = allow_full_lds(reinterpret_cast<const void *>(&p1::ssqp_phase1_kernel), &ldsSet);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(p1::ssqp_phase1_kernel, dim3(nprob), dim3(p1::NT1), lds, stream, P);
     return hipGetLastError();

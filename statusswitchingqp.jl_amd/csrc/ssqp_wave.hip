@@ -842,6 +842,7 @@ struct WCtx {
     const double *__restrict__ uhi;
     ssqp_trace *trace;
     int ntrace;
+    double *lamOut, *gamOut;  // this QP's multiplier outputs (null: not requested)
     int RC;
     long long iter, ret;
     int det;
@@ -1485,6 +1486,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
     WPH(7);  // gamma pass
     // ---- KKTchk!  SSQP.jl:136-188
     KeyMin ev{INF, 0x7fffffff};
+    double lamRow = alRow;  // lane w: the multiplier of row w of [A;G] as KKTchk! sees it (0: inactive / no value)
 #pragma unroll
     for (int m = 0; m < NCH; ++m) {
 #pragma unroll
@@ -1577,6 +1579,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
                         wave_sync();
                     }
                     if (lane == 0 && Lda < -tolG) ev = keymin(ev, KeyMin{Lda, N + w - M});
+                    lamRow = (lane == w) ? Lda : lamRow;
                 }
             }
         }
@@ -1604,7 +1607,21 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
         if (trace && lane == 0) *trace = ssqp_trace{K, W, 2, ev.ord + 1};
         return W_CONTINUE;
     }
-    // ---- optimal: polishSz!  SSQP.jl:10-32
+    // ---- optimal: the multipliers of this pass leave the kernel when asked for (alphaL SSQP.jl:351, gamma :352)
+    if (C.lamOut && lane < MJ) C.lamOut[lane] = lamRow;
+    if (C.gamOut) {
+#pragma unroll
+        for (int m = 0; m < NCH; ++m) {
+            const int r = 2 * lane + 128 * m;
+            if (r < N) {
+                double2 gg;
+                gg.x = (st_of(S.Sp, 2 * m) != SSQP_IN) ? gam[m].x : 0.0;
+                gg.y = (st_of(S.Sp, 2 * m + 1) != SSQP_IN) ? gam[m].y : 0.0;
+                *reinterpret_cast<double2 *>(C.gamOut + r) = gg;
+            }
+        }
+    }
+    // ---- polishSz!  SSQP.jl:10-32
     {
         unsigned long long sn[2] = {0ull, 0ull};
         bool snap[2] = {false, false}, sup[2] = {false, false};
@@ -1829,6 +1846,8 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     C.uhi = P.u + (size_t)prob * P.su;
     C.trace = P.trace ? P.trace + (size_t)prob * P.ntrace : nullptr;
     C.ntrace = P.ntrace;
+    C.lamOut = P.lamOut ? P.lamOut + (size_t)prob * MJ : nullptr;
+    C.gamOut = P.gamOut ? P.gamOut + (size_t)prob * N : nullptr;
     C.RC = P.waveRC;
     C.iter = 0;
     C.ret = 0; C.det = SSQP_DETAIL_NONE;
@@ -1965,6 +1984,15 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
                 }
                 if (done) {
                     if (trace && lane == 0) *trace = ssqp_trace{0, 0, 3, 0};
+                    // (no multipliers exist on this exit of the reference: gamma = V z + q, what freeK! tested; lambda = 0)
+                    if (C.lamOut && lane < MJ) C.lamOut[lane] = 0.0;
+                    if (C.gamOut) {
+#pragma unroll
+                        for (int m = 0; m < NCH; ++m) {
+                            const int r = 2 * lane + 128 * m;
+                            if (r < N) *reinterpret_cast<double2 *>(C.gamOut + r) = S.hq[m];
+                        }
+                    }
                     C.ret = C.iter;  // SSQP.jl:281 (no polishSz! on this exit)
                     step = 1;
                     break;
@@ -2117,8 +2145,8 @@ __global__ __launch_bounds__(64, WPS) void ssqp_wave_kernel(SolveParams P) {
 #endif
 
 hipError_t WV_LAUNCH(const SolveParams &P, int grid, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&WV_KERNEL),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, P.waveLdsBytes);
+    static unsigned long long ldsSet = 0ull;
+    hipError_t e = allow_full_lds(reinterpret_cast<const void *>(&WV_KERNEL), &ldsSet);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(WV_KERNEL, dim3(grid), dim3(64), (size_t)P.waveLdsBytes, stream, P);
     return hipGetLastError();

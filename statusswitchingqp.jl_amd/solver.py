@@ -202,8 +202,9 @@ def phase1_batch(prob, settingsLP=None, nthreads=0):
     return x0, S, st
 
 
-def solveQP_batch(prob, S, x0, settings=None, ctx=None, want_stats=False):
-    """Hot path on a batch held in host memory.  Returns z (P,N), S (P,N+J) copy, status (P,), detail (P,)[, stats]."""
+def solveQP_batch(prob, S, x0, settings=None, ctx=None, want_stats=False, want_mult=False):
+    """Hot path on a batch held in host memory.  Returns z (P,N), S (P,N+J) copy, status (P,), detail (P,)[, stats]
+    [, lambda (P,M+J), gamma (P,N): the multipliers of the last pass by row / variable id, include/ssqp_hip.h]."""
     ctx = ctx or default_context()
     P, N = prob["q"].shape
     M, J = prob["b"].shape[1], prob["g"].shape[1]
@@ -215,12 +216,19 @@ def solveQP_batch(prob, S, x0, settings=None, ctx=None, want_stats=False):
     detail = np.zeros(P, dtype=np.int32)
     stats = (_capi.CStats * P)()
     cs = _csettings(settings)
+    lam = np.zeros((P, M + J)) if want_mult else None
+    gam = np.zeros((P, N)) if want_mult else None
     rc = _capi.lib().ssqp_solve_batch_f64(ctx.handle, P, N, M, J, *[_p(a) for a in arrs], _p(S), _p(x0), _p(z),
-                                          C.byref(cs), _p(status), _p(detail), C.cast(stats, C.c_void_p))
+                                          C.byref(cs), _p(status), _p(detail), C.cast(stats, C.c_void_p),
+                                          lam.ctypes.data_as(C.c_void_p) if want_mult else None,
+                                          gam.ctypes.data_as(C.c_void_p) if want_mult else None)
     _capi.check(rc, ctx.handle)
+    out = (z, S, status, detail)
     if want_stats:
-        return z, S, status, detail, stats_to_numpy(stats)
-    return z, S, status, detail
+        out += (stats_to_numpy(stats),)
+    if want_mult:
+        out += (lam, gam)
+    return out
 
 
 class ResidentBatch:
@@ -326,14 +334,29 @@ class DeviceBatch:
             _capi.check(rc, self.ctx.handle)
         self.S0 = torch.from_numpy(np.ascontiguousarray(S0, dtype=np.int32)).to(dev)
         self.x0 = torch.from_numpy(_f64(x0)).to(dev)
-        self.S = torch.empty_like(self.S0)
-        self.z = torch.zeros((self.P, self.N), dtype=torch.float64, device=dev)
-        self.status = torch.zeros(self.P, dtype=torch.int64, device=dev)
+        self._alloc_outputs(dev)
         self.detail = torch.zeros(self.P, dtype=torch.int32, device=dev)
         self.stats = torch.zeros((self.P, STATS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
         self.ntrace = int(ntrace)
         self.trace = torch.zeros((self.P, max(self.ntrace, 1), 4), dtype=torch.int32, device=dev)
+        self.lam = self.gam = None   # multiplier outputs (want_multipliers())
         torch.cuda.synchronize(dev)
+
+    def want_multipliers(self):
+        """Allocate the optional multiplier outputs: lambda (P, M+J) and gamma (P, N), filled by every solve()."""
+        torch = self.torch
+        dev = self.S.device
+        self.lam = torch.zeros((self.P, max(self.M + self.J, 1)), dtype=torch.float64, device=dev)
+        self.gam = torch.zeros((self.P, self.N), dtype=torch.float64, device=dev)
+        return self
+
+    def _alloc_outputs(self, dev):
+        """z, S, status are views of ONE byte buffer (`out`): the final gather of a sharded batch sends it as it is
+        (dist.PackedGather: one collective, no packing copy)"""
+        from . import dist as _dist
+        torch = self.torch
+        self.out = torch.zeros(_dist.packed_layout(self.P, self.N, self.J)[3], dtype=torch.uint8, device=dev)
+        self.z, self.S, self.status = _dist.packed_views(self.out, self.P, self.N, self.J)
 
     def twin(self, ctx):
         """A second launch lane over the SAME inputs (V, A, G, ..., S0, x0 are shared, not copied) with its own
@@ -344,13 +367,12 @@ class DeviceBatch:
         o.torch, o.ctx = torch, ctx
         o.P, o.N, o.M, o.J = self.P, self.N, self.M, self.J
         o.t, o.S0, o.x0 = self.t, self.S0, self.x0
-        o.S = torch.empty_like(self.S0)
-        o.z = torch.zeros_like(self.z)
-        o.status = torch.zeros_like(self.status)
+        o._alloc_outputs(self.S0.device)
         o.detail = torch.zeros_like(self.detail)
         o.stats = torch.zeros_like(self.stats)
         o.ntrace = self.ntrace
         o.trace = torch.zeros_like(self.trace)
+        o.lam = o.gam = None
         torch.cuda.synchronize(self.S0.device)
         return o
 
@@ -383,7 +405,8 @@ class DeviceBatch:
             self.ctx.handle, self.P, self.N, self.M, self.J, *[self._ptr(t[k]) for k in "VAGqbgdu"], C.byref(strides),
             self._ptr(self.S), self._ptr(self.x0), self._ptr(self.z), C.byref(cs), self._ptr(self.status),
             self._ptr(self.detail), self._ptr(self.stats), self._ptr(self.trace) if self.ntrace else None,
-            self.ntrace, C.c_void_p(stream))
+            self.ntrace, self._ptr(self.lam) if self.lam is not None else None,
+            self._ptr(self.gam) if self.gam is not None else None, C.c_void_p(stream))
         _capi.check(rc, self.ctx.handle)
 
     def phase1(self, settingsLP=None, stream=None):
@@ -410,5 +433,9 @@ class DeviceBatch:
         self.torch.cuda.synchronize(self.S.device)
         stats = np.frombuffer(self.stats.cpu().numpy().tobytes(), dtype=STATS_DTYPE).copy()
         trace = self.trace.cpu().numpy() if self.ntrace else None
-        return dict(z=self.z.cpu().numpy(), S=self.S.cpu().numpy(), status=self.status.cpu().numpy(),
-                    detail=self.detail.cpu().numpy(), stats=stats, trace=trace)
+        out = dict(z=self.z.cpu().numpy(), S=self.S.cpu().numpy(), status=self.status.cpu().numpy(),
+                   detail=self.detail.cpu().numpy(), stats=stats, trace=trace)
+        if self.lam is not None:
+            out["lam"] = self.lam.cpu().numpy()[:, :self.M + self.J]
+            out["gam"] = self.gam.cpu().numpy()
+        return out

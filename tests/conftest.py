@@ -18,7 +18,12 @@ def pkg():
     import __graft_entry__ as ge
     # always the incremental make (a no-op when up to date): the tests never validate a stale binary
     ge.build()
-    return ge.load_package()
+    p = ge.load_package()
+    # ... and say so: the binary names the sources it was built from (csrc/Makefile: HASHED)
+    import bench
+    ver = p._capi.lib().ssqp_version().decode()
+    assert ver.endswith("src=" + bench.kernel_source_hash()), "libssqp_hip.so is stale: %s" % ver
+    return p
 
 
 @pytest.fixture(scope="session")

@@ -27,4 +27,8 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["all_converged"] and d["value"] > 0 and d["pipeline"]["lanes_agree"]
+    assert d["n_gpus"] == 2 and d["all_converged"] and d["value"] > 0 and d["pipeline"]["batches_distinct"]
+    # ONE collective per timed step, issued inside the timed region, and nothing allocated there (pre-allocated
+    # receive buffers; the send side is the batch's packed output buffer)
+    assert d["collective"]["gathers"] == 2 and d["collective"]["per_step"] == 1
+    assert d["collective"]["cuda_allocations_in_timed_region"] == 0, d["collective"]

@@ -108,3 +108,58 @@ def test_sharded_solve_and_gather_equals_unsharded(tmp_path):
     z, S, status, _, _ = orc.solveQP_warm_batch(*[prob[k] for k in "VAGqbgdu"], S0, x0, nthreads=1)
     assert np.array_equal(r["status"], status[:nprob]) and np.array_equal(r["S"], S[:nprob])
     assert np.array_equal(r["z"], z[:nprob])
+
+
+def _worker_packed(rank, world, port, steps, out):
+    """the steady-state form bench.py uses: outputs packed in one buffer, ONE pre-allocated collective per step"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P, N, J = 5, 6, 3
+    total = pkg.dist.packed_layout(P, N, J)[3]
+    send = torch.zeros(total, dtype=torch.uint8)
+    z, S, st = pkg.dist.packed_views(send, P, N, J)
+    pg = pkg.dist.PackedGather(P, N, J, "cpu")
+    recv_ptr = pg.recv.data_ptr()
+    ncalls = [0]
+    real = dist.all_gather_into_tensor
+
+    def counting(*a, **k):
+        ncalls[0] += 1
+        return real(*a, **k)
+    dist.all_gather_into_tensor = counting
+    for step in range(steps):
+        z.copy_(torch.arange(P * N, dtype=torch.float64).view(P, N) + 1000.0 * rank + 0.5 * step)
+        S.copy_(torch.full((P, N + J), rank * 10 + step, dtype=torch.int32))
+        st.copy_(torch.arange(P, dtype=torch.int64) + 100 * rank + step)
+        pg.gather(send)
+    dist.all_gather_into_tensor = real
+    assert ncalls[0] == steps and pg.calls == steps and pg.recv.data_ptr() == recv_ptr   # one collective per step, same buffer
+    gz, gS, gst = pg.results()
+    if rank == 0:
+        np.savez(out, z=gz.numpy(), S=gS.numpy(), status=gst.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_packed_gather_one_collective_per_step(tmp_path):
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "p.npz")
+    steps = 3
+    mp.spawn(_worker_packed, args=(2, port, steps, out), nprocs=2, join=True)
+    r = np.load(out)
+    P, N, J = 5, 6, 3
+    assert r["z"].shape == (2 * P, N) and r["S"].shape == (2 * P, N + J) and r["status"].shape == (2 * P,)
+    for rank in range(2):
+        blk = slice(rank * P, (rank + 1) * P)
+        assert np.array_equal(r["z"][blk], np.arange(P * N).reshape(P, N) + 1000.0 * rank + 0.5 * (steps - 1))
+        assert (r["S"][blk] == rank * 10 + steps - 1).all()
+        assert np.array_equal(r["status"][blk], np.arange(P) + 100 * rank + steps - 1)

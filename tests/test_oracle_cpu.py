@@ -106,3 +106,30 @@ def test_status_codes(orc):
     Vbad = c["V"] - 10.0 * np.eye(20)                          # indefinite: cholesky(V[F,F]) would throw
     z, S, status, det, _ = orc.solveQP_warm(Vbad, *args[1:], c["S0"], c["x0"])
     assert status == -1 and det == 1
+
+
+def test_oracle_multipliers_satisfy_stationarity(pkg, orc):
+    """the multipliers the oracle exports (alphaL SSQP.jl:351, gamma :352, purged rows :158-159) are checked by the
+    mathematics, not by reading the code: V z + q + [A;G]' lambda = gamma on every variable, gamma = 0 on the free
+    ones, signs as KKTchk! demands at an optimum, no multiplier on an inactive row"""
+    from conftest import colmajor
+    tolG = 2.0 ** -33
+    for cfg, seed in [(pkg.GenConfig(40, 1, 0, 80, 1e-3, 3 / 32, 1.2, 0.0), 11),
+                      (pkg.GenConfig(64, 1, 6, 128, 1e-3, 0.07, 0.97, 0.1), 12),
+                      (pkg.GenConfig(48, 3, 5, 96, 1e-3, 0.1, 1.0, 0.1), 13)]:
+        prob = pkg.generate_batch(cfg, 6, 3000 + seed)
+        x0, S0, st = pkg.phase1_batch(prob, nthreads=2)
+        z, S, status, _, _, lam, gam = orc.solveQP_warm_batch(prob["V"], prob["A"], prob["G"], prob["q"], prob["b"],
+                                                             prob["g"], prob["d"], prob["u"], S0, x0, want_mult=True)
+        assert (status > 0).all()
+        N, M, J = cfg.N, cfg.M, cfg.J
+        for p in range(6):
+            C = np.vstack([colmajor(prob["A"][p], M), colmajor(prob["G"][p], J)])
+            res = prob["V"][p] @ z[p] + prob["q"][p] + C.T @ lam[p] - gam[p]
+            assert np.abs(res).max() < 1e-10, np.abs(res).max()
+            Sz = S[p][:N]
+            assert (gam[p][Sz == 0] == 0).all()
+            assert (gam[p][Sz == 2] <= tolG).all() and (gam[p][Sz == 1] >= -tolG).all()
+            assert (lam[p][M:] >= -tolG).all()
+            slack = prob["g"][p] - C[M:] @ z[p]
+            assert (lam[p][M:][slack > 1e-7] == 0).all()
