@@ -160,7 +160,10 @@ def run(args):
     # wavefronts per CU of the wavefront kernel: with several batches in flight two per SIMD (8 per CU) give more QPs/s;
     # a single 1024-QP launch fills 4 per CU exactly and runs fastest with one per SIMD (include/ssqp_hip.h)
     MODES = {"lanes": dict(lazy_handover=1, wave_qp_per_cu=8), "serial": dict(lazy_handover=0, wave_qp_per_cu=0)}
-    state = dict(mode="serial", step=0, gathers=0)
+    state = dict(mode="serial", step=0, gathers=0, coll_allocs=0)
+
+    def n_allocs():
+        return torch.cuda.memory_stats(dev).get("allocation.all.allocated", 0)
     owed = [False] * nlanes                 # lanes whose last solve has not been gathered yet
 
     def set_mode(mode):
@@ -183,8 +186,10 @@ def run(args):
         ln.ctx.flush()                      # (lazy hand-over: an owed workgroup-kernel launch goes out first)
         st = lane_stream(i)
         comm.wait_stream(st)
+        a0 = n_allocs()
         with torch.cuda.stream(comm):
             ln.pg.gather(ln.batch.out)
+        state["coll_allocs"] += n_allocs() - a0     # (what the backend allocates inside the collective call itself)
         st.wait_stream(comm)
         owed[i] = False
         state["gathers"] += 1
@@ -217,9 +222,10 @@ def run(args):
         torch.cuda.synchronize(dev)
 
     def timed(nsteps, events=None):
+        fence()
         state["step"] = 0
         state["gathers"] = 0
-        fence()
+        state["coll_allocs"] = 0
         t = time.perf_counter()
         for _ in range(nsteps):
             step(events)
@@ -247,15 +253,22 @@ def run(args):
     qpc_timed = 8 if mode == "lanes" else (8 if P > 4 * 256 else 4)
 
     # ---- the timed region
-    alloc0 = torch.cuda.memory_stats(dev).get("allocation.all.allocated", 0)
+    timed(0)                                                 # (settle: the counters below cover the timed steps only)
+    alloc0 = n_allocs()
     events = []
     elapsed = timed(args.steps, events)
-    alloc1 = torch.cuda.memory_stats(dev).get("allocation.all.allocated", 0)
+    alloc1 = n_allocs()
     assert world == 1 or state["gathers"] == args.steps, (state["gathers"], args.steps)   # one gather per timed step, all inside
-    launch_ms = [e0.elapsed_time(e1) for e0, e1 in events]   # HIP events on the stream each launch went to
-    k_ms = float(np.mean(launch_ms))
-    in_flight = float(np.sum(launch_ms)) * 1e-3 / elapsed    # launches in flight on average (lanes overlap)
-    # kernel duration of the LAST timed step: HIP events the library records around the solve kernel itself
+    launch_ms = [e0.elapsed_time(e1) for e0, e1 in events]   # whole solve() calls: S reset, counters, prep kernel, solve kernels
+    # the solve kernels alone: HIP events the library records around them on the stream of each launch (it keeps the
+    # pairs of the last 16 launches per context) -- every timed launch, or the most recent 16 per lane
+    kern_ms = []
+    for i, ln in enumerate(lanes):
+        n_i = len(range(i, args.steps, nlanes))
+        if n_i:
+            kern_ms += ln.ctx.recent_kernel_ms(min(n_i, 16))
+    k_ms = float(np.mean(kern_ms))
+    in_flight = k_ms * args.steps * 1e-3 / elapsed           # launches in flight on average (lanes overlap)
     last_kernel_ms = lanes[(args.steps - 1) % nlanes].ctx.last_kernel_ms()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if not rehearsal else "cpu")
@@ -395,9 +408,11 @@ def run(args):
     out = None
     if rank == 0:
         qps = world * P * args.steps / elapsed
-        kname_wave = "ssqp_wave_kernel<%s>" % ("2, true" if qpc_timed == 8 else "1, false")
-        if wave_share > 0 and handed_over == P:
-            kname = "ssqp_wave_kernel<1, false, big factor>" if big_wave == P else "ssqp_solve_kernel (every QP handed over by %s)" % kname_wave
+        kname_wave = "ssqp_wave_kernel<%s>" % ("2, true, 2" if qpc_timed == 8 else "1, false, 2")
+        if wave_share > 0 and handed_over > P // 2:
+            kname = "ssqp_solve_kernel (QPs handed over by the wavefront kernel)"
+        elif wave_share > 0 and big_wave > P // 2:
+            kname = "ssqp_wave_kernel<1, false, 4> (big-factor build, after %s)" % kname_wave
         elif wave_share > 0:
             kname = kname_wave
         else:
@@ -412,8 +427,9 @@ def run(args):
                 "achieved_from_traffic": None if traffic is None else traffic * conc / (k_ms * 1e-3) / 1e9,
                 "frac_from_traffic": None if traffic is None else traffic * conc / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "hot_set_in_flight_bytes": hot_set,
-                "note": "the kernel and launch mode `value` was timed on.  kernel_ms = average launch duration over the "
-                        "timed region (HIP events on the stream each launch went to); achieved = alg_bytes_per_launch x "
+                "note": "the kernel and launch mode `value` was timed on.  kernel_ms = average duration of the solve "
+                        "kernel over the launches of the timed region (HIP events the library records around it on the "
+                        "stream each launch went to); achieved = alg_bytes_per_launch x "
                         "max(1, launches_in_flight) / kernel_ms, launches_in_flight = sum of launch durations / wall time "
                         "(launch lanes overlap: a launch shares the chip with its neighbours, so bytes / its own duration "
                         "would understate the rate the chip moves bytes at; with serial launches the factor is 1).  "
@@ -451,7 +467,8 @@ def run(args):
             "pipeline": {"mode": mode, "streams": nlanes if mode == "lanes" else 1, "batches": nlanes,
                          "batches_distinct": distinct, "probe_ms_per_step": {k: 1e3 * v for k, v in probe.items()},
                          "kernel_ms_last_timed_launch": last_kernel_ms,
-                         "launch_ms_min_max": [float(np.min(launch_ms)), float(np.max(launch_ms))],
+                         "kernel_ms_min_max": [float(np.min(kern_ms)), float(np.max(kern_ms))],
+                         "solve_call_ms_mean": float(np.mean(launch_ms)),
                          "note": "steps are independent batches (one distinct batch per lane, own seeds); mode lanes = "
                                  "issued round-robin on `streams` HIP streams (one context per lane), the drain of one "
                                  "launch overlaps the ramp-up of the next; mode serial = the same batches one after the "
@@ -459,7 +476,11 @@ def run(args):
                                  "every step solves all its QPs from (x0, S0)"},
             "collective": {"gathers": state["gathers"], "per_step": 1 if world > 1 else 0,
                            "bytes_per_rank_per_step": (lanes[0].pg.bytes if world > 1 else 0),
-                           "cuda_allocations_in_timed_region": int(alloc1 - alloc0)},
+                           "cuda_allocations_in_timed_region": int(alloc1 - alloc0),
+                           "of_which_inside_the_backend_collective_call": int(state["coll_allocs"]),
+                           "note": "one all_gather_into_tensor of the packed (z, S, status) per step into a receive buffer "
+                                   "allocated once; this code allocates nothing per step (the gloo backend of the "
+                                   "rehearsal mode stages device tensors through temporaries of its own)"},
             "roofline": roof,
             "roofline_issue": issue,
             "roofline_serial": roof_serial,

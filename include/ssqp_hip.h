@@ -80,7 +80,8 @@ typedef struct ssqp_stats {
     int32_t max_k;      /* largest free set seen */
     int32_t path;       /* bit0: LDS factor path used, bit1: global-scratch path, bit2: kept-factor engine, bit3: kept
                            factor migrated to the global arena, bit4: wavefront-per-QP kernel, bit5: handed over
-                           from the wavefront kernel to the workgroup kernel */
+                           from the wavefront kernel to the workgroup kernel, bit6: continued in the big-factor build
+                           of the wavefront kernel after a hand-over from the build it started in */
 } ssqp_stats;
 
 /* one record per loop pass when tracing is requested */
@@ -102,8 +103,12 @@ const char *ssqp_last_error(const ssqp_ctx *ctx);
 /* Per-context switches (never read from the environment; a context belongs to one host thread at a time).
  * The reference's Settings (src/types.jl:390-397) stay free of backend fields.
  *   "wave_kernel"     1 (default): QPs of a shape the wavefront-per-QP kernel takes (N even <= 512, M+J <= 11)
- *                     run there and are handed over to the workgroup kernel only when their free set outgrows
- *                     it; 0: workgroup kernel only
+ *                     run there: they start in the build "wave_qp_per_cu" selects (factor of up to 92 / 127 rows), a QP
+ *                     whose free set outgrows that continues in the big-factor build (four row slots, up to 252 free
+ *                     variables, rows >= 64 of the factor in global scratch) and only beyond that in the workgroup
+ *                     kernel -- every hand-over passes (z, S, pass count), the loop has no other state;
+ *                     2: start in the big-factor build (workloads known to end with large free sets);
+ *                     0: workgroup kernel only
  *   "wave_qp_per_cu"  QPs (wavefronts) per CU of that kernel: 4 = one per SIMD, 512 registers, the factor (up to 92 rows)
  *                     in LDS -- the lowest latency per QP; 8 = two per SIMD, 256 registers, rows >= 64 of the factor (and,
  *                     between the passes that use it, the second row slot) in global scratch, up to 127 rows -- more
@@ -226,9 +231,12 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *ctx, int nprob, int N, int M, int
 int ssqp_flush(ssqp_ctx *ctx);
 /* waits for `stream`; with "lazy_handover" it first issues the launch the last call on ctx may still owe */
 int ssqp_sync(ssqp_ctx *ctx, void *stream);
-/* duration in ms of the solve kernel of the most recent ssqp_solve_batch_dev_f64
+/* duration in ms of the solve kernel(s) of the most recent ssqp_solve_batch_dev_f64
  * on this ctx, from HIP events recorded on the launch stream (call after sync) */
 int ssqp_last_kernel_ms(ssqp_ctx *ctx, float *ms);
+/* the same for the launch `back` launches before the most recent one on this ctx (0 = the most recent; the library keeps
+ * the event pairs of the last 16 launches): how a host reads the durations of launches it issued back to back */
+int ssqp_recent_kernel_ms(ssqp_ctx *ctx, int back, float *ms);
 
 /* ---- Phase-1: replaces initQP(Q, settingsLP), SSQP.jl:461-560 (host C++) -- */
 /* *status: 1 feasible, 0 infeasible, -1 basis singular. */

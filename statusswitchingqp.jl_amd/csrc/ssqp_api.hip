@@ -24,29 +24,32 @@ struct ssqp_ctx {
     int device = 0;
     int numCU = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    // begin / end events of the solve kernels of the last EV_RING launches (ssqp_last_kernel_ms, ssqp_recent_kernel_ms)
+    static constexpr int EV_RING = 16;
+    hipEvent_t evB[EV_RING] = {}, evE[EV_RING] = {};
+    unsigned long long nLaunch = 0;   // launches so far; launch k uses slot k % EV_RING
     std::string err;
     // options (ssqp_ctx_set_option): algorithm switches are per context, never read from the environment
     int optWgPerCU = 0;      // 0 = automatic
     int optDenseGamma = 0;   // 1: dense (reference-shaped) formulation -- roofline measurements
     int optIncremental = 1;  // 0: refactor V[F,F] from scratch in every pass
-    int optWaveKernel = 1;   // 0: never use the wavefront-per-QP kernel
+    int optWaveKernel = 1;   // 0: never use the wavefront-per-QP kernel; 2: start in its big-factor build
     int optWaveQPC = 0;      // QPs (wavefronts) per CU of the wavefront kernel: 0 = by batch size, 1..4, 8
     int optLazyHandover = 0; // 1: the hand-over launch is deferred to ssqp_sync / the next call and skipped when empty
     int optPinHost = 0;      // 1: page-lock the caller's V array (kept registered until another array comes)
     const void *pinnedPtr = nullptr;
     size_t pinnedBytes = 0;
     // grow-only device workspaces
-    DevBuf Ct, rhs, queue, gscratch, fbList, fbIter, wscratch, p1ws, p1wsInt;
+    DevBuf Ct, rhs, queue, gscratch, fbList, fbList2, fbIter, wscratch, wscratchBig, p1ws, p1wsInt;
     // staging buffers of the host-pointer entry points
     DevBuf hV, hA, hG, hq, hb, hg, hd, hu, hS, hx0, hz, hstatus, hdetail, hstats, hlam, hgam;
     // lazy hand-over: the launch the wavefront kernel may still owe (its hand-over count lands in pinned memory)
     unsigned int *hostCount = nullptr;   // pinned
     hipEvent_t evCount = nullptr;
     bool pending = false;
-    ssqp::SolveParams pendP;
-    int pendGrid = 0, pendWg = 0;
+    ssqp::SolveParams pendP;          // parameters of the workgroup-kernel stage
+    ssqp::SolveParams pendBig;        // ... of the big-factor wavefront stage in front of it (pendBigGrid > 0)
+    int pendGrid = 0, pendWg = 0, pendBigGrid = 0, pendSlot = 0;
     size_t pendLds = 0;
     hipStream_t pendStream = nullptr;
     hipStream_t owedStream = nullptr;    // stream an owed hand-over launch went out on (ordered before the next call's resets)
@@ -124,9 +127,11 @@ int ssqp_ctx_create(int device, ssqp_ctx **out) {
         return SSQP_ERR_NO_DEVICE;
     }
     c->numCU = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
-        delete c;
+    bool evOk = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < ssqp_ctx::EV_RING && evOk; ++k)
+        evOk = hipEventCreate(&c->evB[k]) == hipSuccess && hipEventCreate(&c->evE[k]) == hipSuccess;
+    if (!evOk) {
+        (void)ssqp_ctx_destroy(c);
         return SSQP_ERR_HIP;
     }
     *out = c;
@@ -149,11 +154,13 @@ int ssqp_ctx_destroy(ssqp_ctx *c) {
     c->lanes.clear();
     for (hipEvent_t &e : c->evCopy)
         if (e) (void)hipEventDestroy(e), e = nullptr;
-    for (DevBuf *b : {&c->Ct, &c->rhs, &c->queue, &c->gscratch, &c->fbList, &c->fbIter, &c->wscratch, &c->p1ws, &c->p1wsInt, &c->hV, &c->hA, &c->hG, &c->hq, &c->hb, &c->hg,
+    for (DevBuf *b : {&c->Ct, &c->rhs, &c->queue, &c->gscratch, &c->fbList, &c->fbList2, &c->fbIter, &c->wscratch, &c->wscratchBig, &c->p1ws, &c->p1wsInt, &c->hV, &c->hA, &c->hG, &c->hq, &c->hb, &c->hg,
                       &c->hd, &c->hu, &c->hS, &c->hx0, &c->hz, &c->hstatus, &c->hdetail, &c->hstats, &c->hlam, &c->hgam})
         release(*b);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int k = 0; k < ssqp_ctx::EV_RING; ++k) {
+        if (c->evB[k]) (void)hipEventDestroy(c->evB[k]);
+        if (c->evE[k]) (void)hipEventDestroy(c->evE[k]);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SSQP_OK;
@@ -180,8 +187,8 @@ int ssqp_ctx_set_option(ssqp_ctx *c, const char *name, int value) {
     }
     if ((slot == &c->optWgPerCU && (value < 0 || value > ssqp::MAX_WG_PER_CU)) ||
         (slot == &c->optWaveQPC && (value < 0 || value > 8)) ||
-        ((slot == &c->optDenseGamma || slot == &c->optIncremental || slot == &c->optWaveKernel || slot == &c->optPinHost ||
-          slot == &c->optLazyHandover) &&
+        (slot == &c->optWaveKernel && (value < 0 || value > 2)) ||
+        ((slot == &c->optDenseGamma || slot == &c->optIncremental || slot == &c->optPinHost || slot == &c->optLazyHandover) &&
          (value != 0 && value != 1))) {
         c->err = std::string("option value out of range: ") + name;
         return SSQP_ERR_ARG;
@@ -210,9 +217,12 @@ static int finish_pending(ssqp_ctx *c) {
     c->pending = false;
     if (!hip_ok(c, hipEventSynchronize(c->evCount), "hipEventSynchronize")) return SSQP_ERR_HIP;
     if (*c->hostCount == 0) return SSQP_OK;
+    if (c->pendBigGrid > 0 &&
+        !hip_ok(c, ssqp::launch_solve_wave(c->pendBig, c->pendBigGrid, 2, c->pendStream), "big-factor wave launch"))
+        return SSQP_ERR_HIP;
     if (!hip_ok(c, ssqp::launch_solve(c->pendP, c->pendGrid, c->pendLds, c->pendWg, c->pendStream), "solve launch"))
         return SSQP_ERR_HIP;
-    if (!hip_ok(c, hipEventRecord(c->ev1, c->pendStream), "hipEventRecord")) return SSQP_ERR_HIP;
+    if (!hip_ok(c, hipEventRecord(c->evE[c->pendSlot], c->pendStream), "hipEventRecord")) return SSQP_ERR_HIP;
     c->owedStream = c->pendStream;
     return SSQP_OK;
 }
@@ -245,19 +255,23 @@ int ssqp_sync(ssqp_ctx *c, void *stream) {
     return hip_ok(c, hipStreamSynchronize(s), "hipStreamSynchronize") ? SSQP_OK : SSQP_ERR_HIP;
 }
 
-int ssqp_last_kernel_ms(ssqp_ctx *c, float *ms) {
-    if (!c || !ms) return SSQP_ERR_ARG;
-    if (!c->timed) {
-        c->err = "no solve has been launched on this context";
+int ssqp_recent_kernel_ms(ssqp_ctx *c, int back, float *ms) {
+    if (!c || !ms || back < 0 || back >= ssqp_ctx::EV_RING) return SSQP_ERR_ARG;
+    if (c->nLaunch <= (unsigned long long)back) {
+        c->err = "no such launch on this context";
         return SSQP_ERR_ARG;
     }
+    if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return SSQP_ERR_HIP;
     {
         const int rcp = finish_pending(c);
         if (rcp != SSQP_OK) return rcp;
     }
-    if (!hip_ok(c, hipEventSynchronize(c->ev1), "hipEventSynchronize")) return SSQP_ERR_HIP;
-    return hip_ok(c, hipEventElapsedTime(ms, c->ev0, c->ev1), "hipEventElapsedTime") ? SSQP_OK : SSQP_ERR_HIP;
+    const int slot = (int)((c->nLaunch - 1 - (unsigned long long)back) % ssqp_ctx::EV_RING);
+    if (!hip_ok(c, hipEventSynchronize(c->evE[slot]), "hipEventSynchronize")) return SSQP_ERR_HIP;
+    return hip_ok(c, hipEventElapsedTime(ms, c->evB[slot], c->evE[slot]), "hipEventElapsedTime") ? SSQP_OK : SSQP_ERR_HIP;
 }
+
+int ssqp_last_kernel_ms(ssqp_ctx *c, float *ms) { return ssqp_recent_kernel_ms(c, 0, ms); }
 
 int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const double *dV, const double *dA,
                                      const double *dG, const double *dq, const double *db, const double *dg,
@@ -308,10 +322,13 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
     if (grid < 1) grid = 1;
     const size_t gstride = ssqp::global_arena_doubles(N, M, J);
     // the wavefront-per-QP kernel takes the shapes it is built for (N even <= 512, M + J <= 11) in the default
-    // formulation; QPs it hands over (free set beyond its factor capacity) continue in the workgroup kernel
+    // formulation.  A QP whose free set outgrows the factor of the build it started in is handed over: builds 0 / 1
+    // (up to 92 / 127 rows) -> the big-factor build (four row slots, up to WAVE_BIG_ROWS rows) -> the workgroup kernel
     const bool useWave = c->optWaveKernel && c->optIncremental && !c->optDenseGamma && ssqp::wave_kernel_applies(N, M, J);
-    int waveGrid = 0, waveRC = 0, waveLds = 0, waveWps = 1;
-    size_t wstride = 0;
+    const bool bigFirst = useWave && c->optWaveKernel == 2;   // start in the big-factor build (option)
+    const bool bigStage = useWave && (bigFirst || N > 92);    // (a smaller N can never outgrow build 0 / 1 ... nearly)
+    int waveGrid = 0, waveRC = 0, waveLds = 0, waveWps = 1, bigGrid = 0;
+    size_t wstride = 0, wstrideBig = 0;
     if (useWave) {
         // 4 per CU (one wavefront per SIMD, 512 registers, everything in LDS) is the faster kernel per QP; 8 per CU (two per
         // SIMD, 256 registers, rows >= 64 of the factor and -- between the passes that use it -- the second row slot in
@@ -332,13 +349,19 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
         }
         waveGrid = c->numCU * qpc;
         if (waveGrid > nprob) waveGrid = nprob;
-        wstride = ssqp::wave_scratch_doubles(N, M, J);
+        wstride = ssqp::wave_scratch_doubles(waveWps == 2 ? 1 : 0);
+        if (bigStage) {  // one wavefront per SIMD (its four row slots take the whole register file)
+            bigGrid = c->numCU * 4;
+            if (bigGrid > nprob) bigGrid = nprob;
+            wstrideBig = ssqp::wave_scratch_doubles(2);
+        }
     }
     if (!ensure(c, c->Ct, (size_t)nprob * MJ * N * 8) || !ensure(c, c->rhs, (size_t)nprob * MJ * 8) ||
         !ensure(c, c->queue, 64) || !ensure(c, c->gscratch, (size_t)grid * gstride * 8))
         return SSQP_ERR_ALLOC;
-    if (useWave && (!ensure(c, c->fbList, (size_t)nprob * 4) || !ensure(c, c->fbIter, (size_t)nprob * 8) ||
-                    !ensure(c, c->wscratch, (size_t)waveGrid * wstride * 8)))
+    if (useWave && (!ensure(c, c->fbList, (size_t)nprob * 4) || !ensure(c, c->fbList2, (size_t)nprob * 4) ||
+                    !ensure(c, c->fbIter, (size_t)nprob * 8) || !ensure(c, c->wscratch, (size_t)waveGrid * wstride * 8) ||
+                    (bigStage && !ensure(c, c->wscratchBig, (size_t)bigGrid * wstrideBig * 8))))
         return SSQP_ERR_ALLOC;
 
     ssqp::SolveParams P;
@@ -363,11 +386,15 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
     P.gscratchStride = gstride;
     P.denseGamma = c->optDenseGamma;
     P.incremental = c->optDenseGamma ? 0 : c->optIncremental;  // the dense run is the from-scratch, reference-shaped pass
-    // queue words: [0] work counter of the wavefront kernel, [1] of the workgroup kernel, [2] hand-over count
-    P.fbCount = (unsigned int *)c->queue.p + 2;
+    // queue words: work counters [0] first wavefront stage, [1] workgroup kernel, [4] big-factor stage;
+    //              hand-over counts [2] out of the first stage, [3] out of the big-factor stage
+    unsigned int *qw = (unsigned int *)c->queue.p;
+    P.fbCount = qw + 2;
     P.fbList = (int *)c->fbList.p;
     P.fbIter = (long long *)c->fbIter.p;
     P.resume = 0;
+    P.resumeCount = nullptr;
+    P.resumeList = nullptr;
     P.wscratch = (double *)c->wscratch.p;
     P.wscratchStride = wstride;
     P.waveLdsBytes = waveLds;
@@ -384,37 +411,65 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
     ssqp::launch_prep(sharedC ? 1 : nprob, sharedR ? 1 : nprob, N, M, J, dA, dG, db, dg, sd->A, sd->G, sd->b, sd->g,
                       (double *)c->Ct.p, (double *)c->rhs.p, s);
     if (!hip_ok(c, hipGetLastError(), "prep launch")) return SSQP_ERR_HIP;
-    if (!hip_ok(c, hipEventRecord(c->ev0, s), "hipEventRecord")) return SSQP_ERR_HIP;
+    const int slot = (int)(c->nLaunch % ssqp_ctx::EV_RING);
+    c->nLaunch += 1;
+    if (!hip_ok(c, hipEventRecord(c->evB[slot], s), "hipEventRecord")) return SSQP_ERR_HIP;
     if (useWave) {
-        P.queue = (unsigned int *)c->queue.p;
-        if (!hip_ok(c, ssqp::launch_solve_wave(P, waveGrid, waveWps == 2 ? 1 : 0, s), "wave solve launch")) return SSQP_ERR_HIP;
-        P.queue = (unsigned int *)c->queue.p + 1;
-        P.resume = 1;  // (a grid that finds the hand-over list empty exits at once)
+        // the big-factor stage: problems from the first stage's hand-over list (or all of them when it goes first)
+        ssqp::SolveParams B = P;
+        B.queue = qw + 4;
+        B.wscratch = (double *)c->wscratchBig.p;
+        B.wscratchStride = wstrideBig;
+        B.waveLdsBytes = ssqp::wave_lds_bytes(0);
+        B.waveRC = N < ssqp::WAVE_BIG_ROWS ? N : ssqp::WAVE_BIG_ROWS;
+        B.resume = bigFirst ? 0 : 1;
+        B.resumeCount = qw + 2;
+        B.resumeList = (const int *)c->fbList.p;
+        B.fbCount = qw + 3;
+        B.fbList = (int *)c->fbList2.p;
+        // the workgroup kernel: what the last wavefront stage could not finish
+        ssqp::SolveParams W = P;
+        W.queue = qw + 1;
+        W.resume = 1;  // (a grid that finds the hand-over list empty exits at once)
+        if (bigStage) {
+            W.fbCount = qw + 3;
+            W.fbList = (int *)c->fbList2.p;
+        }
+        if (bigFirst) {
+            if (!hip_ok(c, ssqp::launch_solve_wave(B, bigGrid, 2, s), "big-factor wave launch")) return SSQP_ERR_HIP;
+        } else {
+            if (!hip_ok(c, ssqp::launch_solve_wave(P, waveGrid, waveWps == 2 ? 1 : 0, s), "wave solve launch")) return SSQP_ERR_HIP;
+        }
         if (c->optLazyHandover) {
-            // The workgroup kernel needs a CU with 80 KiB of LDS and four free register files: behind a launch of another
-            // context it would wait for that even when there is nothing to do.  Lazy mode: the hand-over count comes to
-            // pinned host memory and the launch is issued by ssqp_sync / the next call only if the count is not zero.
+            // The later stages need CUs with free LDS and register files: behind a launch of another context they would
+            // wait for that even when there is nothing to do.  Lazy mode: the hand-over count of the first stage comes to
+            // pinned host memory and the later stages are issued by ssqp_sync / the next call only if it is not zero.
             if (!c->hostCount && !hip_ok(c, hipHostMalloc((void **)&c->hostCount, 64, hipHostMallocDefault), "hipHostMalloc"))
                 return SSQP_ERR_ALLOC;
             if (!c->evCount && !hip_ok(c, hipEventCreateWithFlags(&c->evCount, hipEventDisableTiming), "hipEventCreate"))
                 return SSQP_ERR_HIP;
-            if (!hip_ok(c, hipEventRecord(c->ev1, s), "hipEventRecord")) return SSQP_ERR_HIP;
-            if (!hip_ok(c, hipMemcpyAsync(c->hostCount, P.fbCount, 4, hipMemcpyDeviceToHost, s), "D2H") ||
+            if (!hip_ok(c, hipEventRecord(c->evE[slot], s), "hipEventRecord")) return SSQP_ERR_HIP;
+            if (!hip_ok(c, hipMemcpyAsync(c->hostCount, bigFirst ? B.fbCount : P.fbCount, 4, hipMemcpyDeviceToHost, s), "D2H") ||
                 !hip_ok(c, hipEventRecord(c->evCount, s), "hipEventRecord"))
                 return SSQP_ERR_HIP;
-            c->pendP = P;
+            c->pendP = W;
+            c->pendBig = B;
+            c->pendBigGrid = (bigStage && !bigFirst) ? bigGrid : 0;
             c->pendGrid = grid;
             c->pendWg = wgPerCU;
             c->pendLds = (size_t)lay.total_bytes;
             c->pendStream = s;
+            c->pendSlot = slot;
             c->pending = true;
-            c->timed = true;
             return SSQP_OK;
         }
+        if (bigStage && !bigFirst &&
+            !hip_ok(c, ssqp::launch_solve_wave(B, bigGrid, 2, s), "big-factor wave launch"))
+            return SSQP_ERR_HIP;
+        P = W;
     }
     if (!hip_ok(c, ssqp::launch_solve(P, grid, (size_t)lay.total_bytes, wgPerCU, s), "solve launch")) return SSQP_ERR_HIP;
-    if (!hip_ok(c, hipEventRecord(c->ev1, s), "hipEventRecord")) return SSQP_ERR_HIP;
-    c->timed = true;
+    if (!hip_ok(c, hipEventRecord(c->evE[slot], s), "hipEventRecord")) return SSQP_ERR_HIP;
     return SSQP_OK;
 }
 

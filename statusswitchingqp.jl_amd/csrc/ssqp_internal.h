@@ -53,7 +53,11 @@ struct SolveParams {
     unsigned int *fbCount;   // number of entries of fbList (device counter, zeroed before the launch)
     int *fbList;             // problem ids handed over
     long long *fbIter;       // per problem: loop passes already done
-    int resume;              // workgroup kernel: 1 = take the QPs of fbList (start from P.z, fbIter) instead of 0..nprob-1
+    int resume;              // 1 = take the QPs of a hand-over list (start from P.z, fbIter) instead of 0..nprob-1: the
+                             // workgroup kernel reads (fbCount, fbList); the big-factor wavefront kernel reads
+                             // (resumeCount, resumeList) and hands what it cannot finish over through (fbCount, fbList)
+    const unsigned int *resumeCount;
+    const int *resumeList;
     double *wscratch;        // wavefront kernel: per-wavefront global scratch
     size_t wscratchStride;   // doubles per wavefront
     int waveLdsBytes;        // wavefront kernel: dynamic LDS per wavefront
@@ -160,9 +164,11 @@ constexpr int WAVE_MJ = 11;      // constraint rows carried per free variable (M
 bool wave_kernel_applies(int N, int M, int J);
 // LDS bytes one wavefront needs for a kept factor of `rc` rows in LDS (rc <= 0: rows >= 64 in global scratch)
 int wave_lds_bytes(int rc);
-// doubles of global scratch per wavefront
-size_t wave_scratch_doubles(int N, int M, int J);
-// variant 0: four QPs per CU (one wavefront per SIMD, every row in LDS); 1: eight per CU (rows >= 64 in global scratch)
+// doubles of global scratch per wavefront of build `variant`
+size_t wave_scratch_doubles(int variant);
+constexpr int WAVE_BIG_ROWS = 252;  // row capacity of the big-factor build (four row slots of 64)
+// variant 0: four QPs per CU (one wavefront per SIMD, every row in LDS); 1: eight per CU (rows >= 64 in global scratch);
+// 2: the big-factor build (four row slots, up to WAVE_BIG_ROWS free variables, rows >= 64 in global scratch)
 hipError_t launch_solve_wave(const SolveParams &P, int grid, int variant, hipStream_t stream);
 
 // ---- Phase-1 on the GPU (ssqp_phase1.hip): one workgroup per QP

@@ -48,6 +48,9 @@ static __device__ unsigned long long g_wphase[64];  // (one per build of the ker
 #define WPH(slot) do { } while (0)
 #endif
 
+// Everything below has internal linkage: the three builds of this file define the same names with different row-slot
+// counts (struct layouts differ), and each build's code must stay in its own translation unit.
+namespace {
 namespace wv {
 
 constexpr int MJX = WAVE_MJ;  // constraint rows carried (M + J <= MJX)
@@ -55,7 +58,18 @@ constexpr int NR = MJX + 1;   // border columns: every row of [A;G] and c
 constexpr int CC = MJX;       // index of the c column
 constexpr int NCH = 4;        // dense layout: element i sits in lane (i >> 1) & 63, chunk i >> 7, half i & 1
 constexpr int KSLOT = 64;     // rows per register slot
+// row slots a build carries in registers: 2 (up to 127 rows) for the two builds the headline shapes run on, 4 (up to 255
+// rows) for the big-factor build (SSQP_WAVE_VARIANT 2) that takes over the QPs whose free set outgrows those
+#ifndef SSQP_WAVE_VARIANT
+#define SSQP_WAVE_VARIANT 0
+#endif
+#if SSQP_WAVE_VARIANT == 2
+constexpr int NSL = 4;
+#else
+constexpr int NSL = 2;
+#endif
 [[maybe_unused]] constexpr int WAVE_LS_DOUBLES = 128 * MJX + MJX * MJX + MJX + 21;  // global scratch of the purged-row least squares
+[[maybe_unused]] constexpr int WAVE_LS_DOUBLES_BIG = 256 * MJX + MJX * MJX + MJX + 21;  // ... of the big-factor build (up to 256 rows)
 constexpr double INF = __builtin_huge_val();
 
 // compile-time loop: the body sees its index as a constant, so every register-array index is static whatever
@@ -78,25 +92,44 @@ __device__ __forceinline__ void sfor(F &&f) {
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 template <int SL>
-__device__ __forceinline__ double rbcast(const double (&v)[2], int r) {  // value of row r (uniform r)
+__device__ __forceinline__ double rbcast(const double (&v)[NSL], int r) {  // value of row r (uniform r)
     if (SL == 1) return readlane_f64(v[0], r);
-    const double a = readlane_f64(v[0], r & 63), b = readlane_f64(v[1], r & 63);
-    return (r < KSLOT) ? a : b;
+    if (SL == 2) {
+        const double a = readlane_f64(v[0], r & 63), b = readlane_f64(v[1], r & 63);
+        return (r < KSLOT) ? a : b;
+    }
+    // more slots: r is uniform, so the slot is picked by a scalar branch and one pair of v_readlane runs
+    double x = 0.0;
+    const int l = r & 63;
+    sfor<0, SL>(SFOR_BODY(t) {
+        SFOR_IDX(t);
+        if ((r >> 6) == t) x = readlane_f64(v[t], l);
+    });
+    return x;
 }
 template <int SL>
-__device__ __forceinline__ int rbcast_i(const int (&v)[2], int r) {
+__device__ __forceinline__ int rbcast_i(const int (&v)[NSL], int r) {
     if (SL == 1) return __builtin_amdgcn_readlane(v[0], r);
-    const int a = __builtin_amdgcn_readlane(v[0], r & 63), b = __builtin_amdgcn_readlane(v[1], r & 63);
-    return (r < KSLOT) ? a : b;
+    if (SL == 2) {
+        const int a = __builtin_amdgcn_readlane(v[0], r & 63), b = __builtin_amdgcn_readlane(v[1], r & 63);
+        return (r < KSLOT) ? a : b;
+    }
+    int x = 0;
+    const int l = r & 63;
+    sfor<0, SL>(SFOR_BODY(t) {
+        SFOR_IDX(t);
+        if ((r >> 6) == t) x = __builtin_amdgcn_readlane(v[t], l);
+    });
+    return x;
 }
 template <int SL>
-__device__ __forceinline__ void set_row(double (&v)[2], int r, double x) {
+__device__ __forceinline__ void set_row(double (&v)[NSL], int r, double x) {
     const int lane = lane_id();
 #pragma unroll
     for (int t = 0; t < SL; ++t) v[t] = (lane + KSLOT * t == r) ? x : v[t];
 }
 template <int SL>
-__device__ __forceinline__ void set_row_i(int (&v)[2], int r, int x) {
+__device__ __forceinline__ void set_row_i(int (&v)[NSL], int r, int x) {
     const int lane = lane_id();
 #pragma unroll
     for (int t = 0; t < SL; ++t) v[t] = (lane + KSLOT * t == r) ? x : v[t];
@@ -173,33 +206,35 @@ __device__ __forceinline__ double scan_src_f64(double v, double fill) {
     return __hiloint2double(hi, lo);
 }
 
-// rows p.. move up by one (row r takes row r+1) in a per-row register pair
+// rows p.. move up by one (row r takes row r+1) in a per-row register set
 template <int SL>
-__device__ __forceinline__ void shift_up(double (&v)[2], int p) {
+__device__ __forceinline__ void shift_up(double (&v)[NSL], int p) {
     const int lane = lane_id();
-    const double n0 = lane_next_f64(v[0]);
-    if (SL == 1) {
-        v[0] = (lane >= p) ? n0 : v[0];
-    } else {
-        const double n1 = lane_next_f64(v[1]);
-        const double first1 = readlane_f64(v[1], 0);
-        const double m0 = (lane == 63) ? first1 : n0;
-        v[0] = (lane >= p) ? m0 : v[0];
-        v[1] = (lane + KSLOT >= p) ? n1 : v[1];
+    double n[NSL], first[NSL];
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        n[t] = lane_next_f64(v[t]);
+        first[t] = (t > 0) ? readlane_f64(v[t], 0) : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const double m = (t + 1 < SL && lane == 63) ? first[t + 1] : n[t];  // (lane 63 takes the first row of the next slot)
+        v[t] = (lane + KSLOT * t >= p) ? m : v[t];
     }
 }
 template <int SL>
-__device__ __forceinline__ void shift_up_i(int (&v)[2], int p) {
+__device__ __forceinline__ void shift_up_i(int (&v)[NSL], int p) {
     const int lane = lane_id();
-    const int n0 = lane_next_i32(v[0]);
-    if (SL == 1) {
-        v[0] = (lane >= p) ? n0 : v[0];
-    } else {
-        const int n1 = lane_next_i32(v[1]);
-        const int first1 = __builtin_amdgcn_readlane(v[1], 0);
-        const int m0 = (lane == 63) ? first1 : n0;
-        v[0] = (lane >= p) ? m0 : v[0];
-        v[1] = (lane + KSLOT >= p) ? n1 : v[1];
+    int n[NSL], first[NSL];
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        n[t] = lane_next_i32(v[t]);
+        first[t] = (t > 0) ? __builtin_amdgcn_readlane(v[t], 0) : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int m = (t + 1 < SL && lane == 63) ? first[t + 1] : n[t];
+        v[t] = (lane + KSLOT * t >= p) ? m : v[t];
     }
 }
 
@@ -281,10 +316,10 @@ struct Fac {
 __device__ __forceinline__ int cofs64(int c) { return c * 64 - ((c * (c - 1)) >> 1); }
 
 struct Rows {  // one entry per row of the kept factor = per free variable, row r in lane r & 63 of slot r >> 6
-    int ord[2], rank[2];         // variable index; its rank among the free variables by index (findall order)
-    double zF[2], ur[2], dr[2];  // z, upper and lower bound of the variable
-    double dg[2], rd[2];         // pivot d_r of the LDL' factor and its reciprocal
-    double Y[NR][2];             // forward-substituted border: Y[w] = (L^-1 [A;G][w,F]')_r, Y[CC] = (L^-1 c)_r
+    int ord[NSL], rank[NSL];           // variable index; its rank among the free variables by index (findall order)
+    double zF[NSL], ur[NSL], dr[NSL];  // z, upper and lower bound of the variable
+    double dg[NSL], rd[NSL];           // pivot d_r of the LDL' factor and its reciprocal
+    double Y[NR][NSL];                 // forward-substituted border: Y[w] = (L^-1 [A;G][w,F]')_r, Y[CC] = (L^-1 c)_r
 };
 
 struct WLds {
@@ -304,10 +339,11 @@ struct WLds {
 
 // [A;G][w, ord_r] for this lane's rows (a gather from the contiguous row w of Ct; cold paths only)
 template <int SL>
-__device__ __forceinline__ void gather_X(const double *__restrict__ Ct, int N, int w, const int (&ord)[2], int K,
-                                         double (&x)[2]) {
+__device__ __forceinline__ void gather_X(const double *__restrict__ Ct, int N, int w, const int (&ord)[NSL], int K,
+                                         double (&x)[NSL]) {
     const int lane = lane_id();
-    x[0] = x[1] = 0.0;
+#pragma unroll
+    for (int t = 0; t < NSL; ++t) x[t] = 0.0;
 #pragma unroll
     for (int t = 0; t < SL; ++t) {
         const int r = lane + KSLOT * t;
@@ -316,31 +352,36 @@ __device__ __forceinline__ void gather_X(const double *__restrict__ Ct, int N, i
     }
 }
 
-// one column of the factor for this lane's rows, zero where there is no entry (rows <= c, rows >= K, !valid)
+// one column of the factor for this lane's rows, zero where there is no entry (rows <= c, rows >= K, !valid).
+// Slots that lie wholly above the diagonal (every row <= c) are not read at all (uniform branch).
 template <int SL>
-__device__ __forceinline__ void load_col(const Fac &F, int K, int c, double (&l)[2]) {
+__device__ __forceinline__ void load_col(const Fac &F, int K, int c, double (&l)[NSL]) {
     const int lane = lane_id();
     const bool valid = c < K;
     const int cc = valid ? c : 0;
-    {
+#pragma unroll
+    for (int t = 0; t < NSL; ++t) l[t] = 0.0;
+    if (SL <= 2 || cc < 63) {
         const int c0 = cc < 63 ? cc : 63;
         const double v = F.L0[cofs64(c0) - c0 + (lane > c0 ? lane : c0)];
         l[0] = (valid && lane > cc && lane < K) ? v : 0.0;
     }
-    if (SL == 2) {
-        const int rl = lane < F.R1 ? lane : F.R1 - 1;
-        const double v = F.L1[cc * F.R1 + rl];
-        l[1] = (valid && KSLOT + lane > cc && KSLOT + lane < K) ? v : 0.0;
-    } else {
-        l[1] = 0.0;
+#pragma unroll
+    for (int t = 1; t < SL; ++t) {
+        if (SL <= 2 || KSLOT * t + 63 > cc) {  // (uniform)
+            const int rr = lane + KSLOT * (t - 1);
+            const int rl = rr < F.R1 ? rr : F.R1 - 1;
+            const double v = F.L1[cc * F.R1 + rl];
+            l[t] = (valid && KSLOT * t + lane > cc && KSLOT * t + lane < K) ? v : 0.0;
+        }
     }
 }
 template <int SL>
-__device__ __forceinline__ void load_cols4(const Fac &F, int K, int c0, double (&l)[4][2]) {
+__device__ __forceinline__ void load_cols4(const Fac &F, int K, int c0, double (&l)[4][NSL]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) load_col<SL>(F, K, c0 + u, l[u]);
 }
-// element (r, c), r > c, per-lane r (r may be in either part when SL == 2), uniform c
+// element (r, c), r > c, per-lane r (r may be in any slot), uniform c
 template <int SL>
 __device__ __forceinline__ double fac_get(const Fac &F, int r, int c) {
     const int c0 = c < 63 ? c : 63;
@@ -367,21 +408,23 @@ __device__ __forceinline__ void fac_put(const Fac &F, int r, int c, double v, bo
 // lnew = the new row of L (for the border update).  Returns the new pivot (must be > 0).
 template <int SL>
 __device__ __forceinline__ double append_row(const Fac &F, Rows &R, int K, int j, const double *__restrict__ V, int N,
-                                             double (&lnew)[2], double (&vraw)[2], double (&ysub)[2]) {
+                                             double (&lnew)[NSL], double (&vraw)[NSL], double (&ysub)[NSL]) {
     const int lane = lane_id();
     const double *__restrict__ col = V + (size_t)j * N;
     const double vjj = col[j];
-    double y[2] = {0.0, 0.0};
+    double y[NSL];
+#pragma unroll
+    for (int t = 0; t < NSL; ++t) y[t] = 0.0;
 #pragma unroll
     for (int t = 0; t < SL; ++t) {
         const int r = lane + KSLOT * t;
         const double v = col[r < K ? R.ord[t] : j];
         y[t] = (r < K) ? v : 0.0;
     }
-    vraw[0] = y[0];
-    vraw[1] = y[1];
+#pragma unroll
+    for (int t = 0; t < NSL; ++t) vraw[t] = y[t];
     {
-        double lc[4][2], ln[4][2];
+        double lc[4][NSL], ln[4][NSL];
         load_cols4<SL>(F, K, 0, lc);
         for (int c0 = 0; c0 < K; c0 += 4) {
             load_cols4<SL>(F, K, c0 + 4, ln);
@@ -399,10 +442,11 @@ __device__ __forceinline__ double append_row(const Fac &F, Rows &R, int K, int j
                 for (int t = 0; t < SL; ++t) lc[u][t] = ln[u][t];
         }
     }
-    ysub[0] = y[0];
-    ysub[1] = y[1];
+#pragma unroll
+    for (int t = 0; t < NSL; ++t) ysub[t] = y[t];
     double part = 0.0;
-    lnew[0] = lnew[1] = 0.0;
+#pragma unroll
+    for (int t = 0; t < NSL; ++t) lnew[t] = 0.0;
 #pragma unroll
     for (int t = 0; t < SL; ++t) {
         const int r = lane + KSLOT * t;
@@ -411,7 +455,7 @@ __device__ __forceinline__ double append_row(const Fac &F, Rows &R, int K, int j
         lnew[t] = tr;
         if (K < 64) {
             if (t == 0 && r < K) F.L0[cofs64(r) - r + K] = tr;
-        } else if (SL == 2) {
+        } else if (SL >= 2) {
             if (r < K) F.L1[r * F.R1 + (K - 64)] = tr;
         }
     }
@@ -424,14 +468,14 @@ __device__ __forceinline__ double append_row(const Fac &F, Rows &R, int K, int j
 // row/column is removed from the packed storage.  pv receives p_k = (L33^-1 l)_k in row k (the downdate of H
 // and nothing else needs it); dg/rd of the rows > p are updated in place (still in their OLD positions).
 template <int SL>
-__device__ __forceinline__ void delete_update(const Fac &F, Rows &R, int K, int p, double (&pv)[2], double (&bt)[2]) {
+__device__ __forceinline__ void delete_update(const Fac &F, Rows &R, int K, int p, double (&pv)[NSL], double (&bt)[NSL]) {
     const int lane = lane_id();
-    double w[2];
+    double w[NSL];
     load_col<SL>(F, K, p, w);
-    pv[0] = pv[1] = 0.0;
-    bt[0] = bt[1] = 0.0;
+#pragma unroll
+    for (int t = 0; t < NSL; ++t) pv[t] = bt[t] = 0.0;
     double alpha = rbcast<SL>(R.dg, p);
-    double lc[2], ln[2];
+    double lc[NSL], ln[NSL];
     load_col<SL>(F, K, p + 1, lc);
     for (int k = p + 1; k < K; ++k) {
         load_col<SL>(F, K, k + 1, ln);
@@ -464,7 +508,7 @@ __device__ __forceinline__ void delete_compact(const Fac &F, int K, int p) {
     const int lane = lane_id();
     constexpr int CB = 4;  // columns per read / write round (their storage is disjoint)
     for (int c0 = 0; c0 < p; c0 += CB) {  // columns c < p lose row p: rows r > p move up by one inside the column
-        double a[CB][2];
+        double a[CB][NSL];
 #pragma unroll
         for (int u = 0; u < CB; ++u) {
             const int c = (c0 + u < p) ? c0 + u : c0;
@@ -489,7 +533,7 @@ __device__ __forceinline__ void delete_compact(const Fac &F, int K, int p) {
     // column c -> c - 1, rows r > c -> r - 1, ascending: the target of column c is the storage of column c - 1, which
     // this round (or an earlier one) has already read
     for (int c0 = p + 1; c0 < K; c0 += CB) {
-        double a[CB][2];
+        double a[CB][NSL];
 #pragma unroll
         for (int u = 0; u < CB; ++u) {
             const int c = (c0 + u < K) ? c0 + u : c0;
@@ -531,14 +575,14 @@ __device__ __forceinline__ void border_sweep(const Fac &F, Rows &R, int K, unsig
                     R.Y[w][t] = (r < K) ? v : 0.0;
                 }
             } else {
-                double x[2];
+                double x[NSL];
                 gather_X<SL>(Ct, N, w < MJX ? w : 0, R.ord, K, x);
 #pragma unroll
                 for (int t = 0; t < SL; ++t) R.Y[w][t] = x[t];
             }
         }
     }
-    double lc[4][2], ln[4][2];
+    double lc[4][NSL], ln[4][NSL];
     load_cols4<SL>(F, K, 0, lc);
     for (int c0 = 0; c0 < K; c0 += 4) {
         load_cols4<SL>(F, K, c0 + 4, ln);
@@ -565,9 +609,10 @@ __device__ __forceinline__ void border_sweep(const Fac &F, Rows &R, int K, unsig
 // back substitution L' x = v (unit upper), v in the row registers
 // L(r, c) for uniform r and c = this lane's row index (a gathered row of the factor); 0 where c >= r
 template <int SL>
-__device__ __forceinline__ void load_rowT(const Fac &F, int r, double (&l)[2]) {
+__device__ __forceinline__ void load_rowT(const Fac &F, int r, double (&l)[NSL]) {
     const int lane = lane_id();
-    l[0] = l[1] = 0.0;
+#pragma unroll
+    for (int t = 0; t < NSL; ++t) l[t] = 0.0;
     if (SL == 1) {  // (no branch: rows <= 0 have no live lane)
         const bool live = lane < r;
         const double x = F.L0[live ? cofs64(lane) - lane + r : 0];
@@ -579,17 +624,18 @@ __device__ __forceinline__ void load_rowT(const Fac &F, int r, double (&l)[2]) {
         const bool live = lane < r;
         const double x = F.L0[live ? cofs64(lane) - lane + r : 0];
         l[0] = live ? x : 0.0;
-    } else if (SL == 2) {
-        const double a = F.L1[lane * F.R1 + (r - 64)];  // columns 0..63 all lie left of row r
-        l[0] = a;
-        const bool live = KSLOT + lane < r;
-        const double b = F.L1[(live ? KSLOT + lane : 0) * F.R1 + (r - 64)];
-        l[1] = live ? b : 0.0;
+    } else {
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {  // column lane + 64 t of row r (columns < 64 all lie left of row r)
+            const bool live = KSLOT * t + lane < r;
+            const double b = F.L1[(live ? KSLOT * t + lane : 0) * F.R1 + (r - 64)];
+            l[t] = live ? b : 0.0;
+        }
     }
 }
 template <int SL>
-__device__ __forceinline__ void back_sweep(const Fac &F, int K, double (&v)[2]) {
-    double lc[4][2], ln[4][2];
+__device__ __forceinline__ void back_sweep(const Fac &F, int K, double (&v)[NSL]) {
+    double lc[4][NSL], ln[4][NSL];
 #pragma unroll
     for (int u = 0; u < 4; ++u) load_rowT<SL>(F, K - 1 - u, lc[u]);
     for (int r0 = K - 1; r0 > 0; r0 -= 4) {
@@ -606,7 +652,58 @@ __device__ __forceinline__ void back_sweep(const Fac &F, int K, double (&v)[2]) 
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) lc[u][t] = ln[u][t];
+            for (int t = 0; t < NSL; ++t) lc[u][t] = ln[u][t];
+    }
+}
+
+// The same back substitution for factors whose rows >= 64 live in global memory (the big-factor build): reading a ROW of
+// the column-major storage costs one cache line per lane, so the sweep goes by COLUMNS instead -- column c holds
+// L(r, c) for the rows r > c contiguously, x_c = v_c - sum_{r > c} L(r, c) x_r is a sum over lanes.  Four columns per
+// round: their partial sums over the rows above the block come out of one multi-vector butterfly, the 4 x 4 triangle
+// inside the block is resolved with scalar broadcasts; the next round's columns are requested before this round's sums.
+template <int SL>
+__device__ __forceinline__ void back_sweep_cols(const Fac &F, int K, double (&v)[NSL]) {
+    const int lane = lane_id();
+    if (K <= 1) return;
+    int c0 = (K - 1) & ~3;
+    double lc[4][NSL], ln[4][NSL];
+    load_cols4<SL>(F, K, c0, lc);
+    for (; c0 >= 0; c0 -= 4) {
+        if (c0 >= 4) load_cols4<SL>(F, K, c0 - 4, ln);
+        // partial sums over the rows beyond the block (x final there); the block's own rows are masked out
+        double prod[4], sums[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int t = 0; t < SL; ++t) {
+                const int r = lane + KSLOT * t;
+                sacc = (r >= c0 + 4) ? fma(lc[u][t], v[t], sacc) : sacc;  // (lc is zero for rows >= K)
+            }
+            prod[u] = sacc;
+        }
+        wave_sum_multi<4>(prod, sums);
+        // the block's slot is uniform: 64 is a multiple of 4
+        const int tb = c0 >> 6, l0 = c0 & 63;
+        sfor<0, SL>(SFOR_BODY(t) {
+            SFOR_IDX(t);
+            if (tb == t) {  // uniform
+                double xb[4];
+#pragma unroll
+                for (int u = 3; u >= 0; --u) {
+                    double x = readlane_f64(v[t], l0 + u) - sums[u];
+#pragma unroll
+                    for (int w = 3; w > u; --w) x = fma(-readlane_f64(lc[u][t], l0 + w), xb[w], x);  // L(c0+w, c0+u)
+                    xb[u] = x;  // (rows >= K: v and lc are zero there, x stays 0)
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[t] = (lane == l0 + u) ? xb[u] : v[t];
+            }
+        });
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < NSL; ++t) lc[u][t] = ln[u][t];
     }
 }
 
@@ -927,7 +1024,7 @@ __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int 
     const double cj = C.Ct[(size_t)(lane < MJ ? lane : 0) * N + j];  // column j of [A;G], row w in lane w
     const double uj = C.uhi[j], dj = C.dlo[j];
     const double zj = __hip_atomic_load(zg + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (written by this wavefront earlier)
-    double lnew[2], vraw[2], ysub[2];
+    double lnew[NSL], vraw[NSL], ysub[NSL];
     const double dnew = append_row<SL>(L.F, R, K, j, C.V, N, lnew, vraw, ysub);
     if (!(dnew > 0.0)) return false;
     if (dz != 0.0) {  // uniform
@@ -1000,8 +1097,8 @@ __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int 
 //   v_k = y_k + p_k y_p,   y'_k = v_k - p_k s_k,   s_{k+1} = a_k s_k + beta_k v_k  (s_{p+1} = 0),  a_k = d_k / d'_k:
 // a first-order recurrence = a scan of affine maps over the lanes (six ds_bpermute steps; the multipliers a are shared
 // by all columns).  The results stay in the OLD row positions; the caller shifts the rows up.
-__device__ __forceinline__ void border_update_scan(Rows &R, int K, int p, const double (&pv)[2], const double (&bt)[2],
-                                                   const double (&dgold)[2], int MJ) {
+__device__ __forceinline__ void border_update_scan(Rows &R, int K, int p, const double (&pv)[NSL], const double (&bt)[NSL],
+                                                   const double (&dgold)[NSL], int MJ) {
     const int lane = lane_id();
     const bool on = lane > p && lane < K;
     // inclusive scan of the multipliers; Astep[st] = the multiplier a lane applies to what step st brings in
@@ -1035,7 +1132,7 @@ __device__ __forceinline__ void border_update_scan(Rows &R, int K, int p, const 
 template <int SL>
 __device__ __forceinline__ void fold_block_shift(const WLds &L, Rows &R, int K, int p, int MJ, double dz, double xp) {
     const int lane = lane_id();
-    double lrow[2];
+    double lrow[NSL];
     load_rowT<SL>(L.F, p, lrow);
 #pragma unroll
     for (int t = 0; t < SL; ++t) {
@@ -1058,9 +1155,9 @@ template <int SL>
 __device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p, int MJ, bool downdate, bool scan,
                                            double &gz, double xp) {
     const int lane = lane_id();
-    double pv[2], bt[2], rdold[2], dgold[2];
+    double pv[NSL], bt[NSL], rdold[NSL], dgold[NSL];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NSL; ++t) {
         rdold[t] = R.rd[t];
         dgold[t] = R.dg[t];
     }
@@ -1068,7 +1165,7 @@ __device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p
     if (downdate) {
         // H' = H - g g' / m,  g = [A;G c']' V_FF^-1 e_p = Y' D^-1 f,  m = (V_FF^-1)_pp = f' D^-1 f,
         // f = L^-1 e_p: f_p = 1, f_r = -p_r below (p = L33^-1 l, the vector the rank-1 update walks through)
-        double fr[2], frd[2], msum = 0.0;
+        double fr[NSL], frd[NSL], msum = 0.0;
 #pragma unroll
         for (int t = 0; t < SL; ++t) {
             const int r = lane + KSLOT * t;
@@ -1199,7 +1296,7 @@ struct WState {
     int nShift;         // status switches since hq / bEall were last re-evaluated from (z, S)
     bool hbValid, cDirty;
     // pending changes of F decided by the last pass
-    unsigned long long del0, del1;  // rows to delete (slot 0 / slot 1 lanes)
+    unsigned long long del[NSL];    // rows to delete (lane mask per slot)
     int appJ;                       // variable to append, or -1
     double relDz;                   // the shift of z[appJ] that hq has already followed (0: none)
     double blkDz;                   // the same for the single variable a blocked step sent to a nonzero bound
@@ -1274,7 +1371,9 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
     const double alRow = L.aLrow[lane < MJX ? lane : 0];
     WPH(1);  // Schur gather + lambda
     // ---- alpha = -V_FF^-1 (AE' alphaL + c):  v = D^-1 (Y_A alphaL + y_c), alpha = -L'^-1 v   (SSQP.jl:329-331)
-    double v[2] = {0.0, 0.0};
+    double v[NSL];
+#pragma unroll
+    for (int t = 0; t < NSL; ++t) v[t] = 0.0;
 #pragma unroll
     for (int t = 0; t < SL; ++t) v[t] = R.Y[CC][t];
 #pragma unroll
@@ -1290,13 +1389,14 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
         const int r = lane + KSLOT * t;
         v[t] = (r < K) ? v[t] * R.rd[t] : 0.0;
     }
-    back_sweep<SL>(L.F, K, v);
+    if (NSL > 2 && SL >= 2) back_sweep_cols<SL>(L.F, K, v);  // (rows >= 64 in global memory: by columns)
+    else back_sweep<SL>(L.F, K, v);
     WPH(2);  // v + back substitution
-    double alpha[2], p[2];
+    double alpha[NSL], p[NSL];
     double pa = 0.0;
     int pnan = 0;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) alpha[t] = p[t] = 0.0;
+    for (int t = 0; t < NSL; ++t) alpha[t] = p[t] = 0.0;
 #pragma unroll
     for (int t = 0; t < SL; ++t) {
         const int r = lane + KSLOT * t;
@@ -1317,10 +1417,10 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
 
     WPH(3);  // p, norm, accounting
     if (pinf > tolG && !anyNan) {  // ------------------------ aStep!  SSQP.jl:61-134
-        double Lr[2];
+        double Lr[NSL];
         double lmin = INF;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) Lr[t] = INF;
+        for (int t = 0; t < NSL; ++t) Lr[t] = INF;
 #pragma unroll
         for (int t = 0; t < SL; ++t) {
             const int r = lane + KSLOT * t;
@@ -1353,9 +1453,15 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
         WPH(4);  // aStep ratios + min
         if (L1 < 1.0) {  // blocked  (:98-127)
             int firstId = 0x7fffffff;
-            unsigned long long dm[2] = {0ull, 0ull};
-            bool hit[2] = {false, false};
-            double zstep[2] = {0.0, 0.0};  // z_F + L1 p before the snap
+            unsigned long long dm[NSL];
+            bool hit[NSL];
+            double zstep[NSL];  // z_F + L1 p before the snap
+#pragma unroll
+            for (int t = 0; t < NSL; ++t) {
+                dm[t] = 0ull;
+                hit[t] = false;
+                zstep[t] = 0.0;
+            }
 #pragma unroll
             for (int t = 0; t < SL; ++t) {
                 const int r = lane + KSLOT * t;
@@ -1407,9 +1513,13 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
                 }
             }
             WPH(5);  // blocked: switches + bound shifts
-            S.del0 = dm[0];
-            S.del1 = dm[1];
-            if (__popcll(dm[0]) + __popcll(dm[1]) != 1) S.blkDz = 0.0;
+            int nblk = 0;
+#pragma unroll
+            for (int t = 0; t < NSL; ++t) {
+                S.del[t] = dm[t];
+                nblk += __popcll(dm[t]);
+            }
+            if (nblk != 1) S.blkDz = 0.0;
             if (trace) {
                 int f = firstId;
                 f = min(f, dpp_i32<DPP_XOR1>(f));
@@ -1515,7 +1625,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
 #pragma unroll
                 for (int w = 0; w < MJX; ++w) {
                     if ((kept >> w) & 1u) {
-                        double xw[2];
+                        double xw[NSL];
                         gather_X<SL>(C.Ct, N, w, R.ord, K, xw);
 #pragma unroll
                         for (int t = 0; t < SL; ++t) {
@@ -1553,7 +1663,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
                     if ((kept >> w) & 1u) {
                         Lda = L.aLrow[w];
                     } else {
-                        double xw[2];
+                        double xw[NSL];
                         gather_X<SL>(C.Ct, N, w, R.ord, K, xw);
                         for (int c = 0; c < W; ++c) {  // yq = Q' gv
                             double s = 0.0;
@@ -1623,8 +1733,13 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
     }
     // ---- polishSz!  SSQP.jl:10-32
     {
-        unsigned long long sn[2] = {0ull, 0ull};
-        bool snap[2] = {false, false}, sup[2] = {false, false};
+        unsigned long long sn[NSL];
+        bool snap[NSL], sup[NSL];
+#pragma unroll
+        for (int t = 0; t < NSL; ++t) {
+            sn[t] = 0ull;
+            snap[t] = sup[t] = false;
+        }
 #pragma unroll
         for (int t = 0; t < SL; ++t) {
             const int r = lane + KSLOT * t;
@@ -1653,7 +1768,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
 #pragma unroll
         for (int w = 0; w < MJX; ++w) {
             if (w >= M && w < MJ) {  // S[N+j] = |g_j - G[j,:] z| < tol ? EO : OE   (:28-30)
-                double sz = 0.0, xw[2];
+                double sz = 0.0, xw[NSL];
                 gather_X<SL>(C.Ct, N, w, R.ord, K, xw);
 #pragma unroll
                 for (int t = 0; t < SL; ++t) {
@@ -1679,7 +1794,9 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
     Rows &R = S.R;
     const int MJ = C.MJ;
     WPH_DECL;
-    const int ndel = __popcll(S.del0) + __popcll(S.del1);
+    int ndel = 0;
+#pragma unroll
+    for (int t = 0; t < NSL; ++t) ndel += __popcll(S.del[t]);
     if (ndel > 0) {
         S.certMask = 0u;  // (a column of AE goes: the Gram pivots may shrink)
         const bool single = (ndel == 1);
@@ -1687,12 +1804,13 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
         // the variable went to a nonzero bound the change of c is folded in beforehand -- no re-gather, no re-sweep.
         const bool fast = single && SL == 1 && (!S.cDirty || S.blkDz != 0.0);
         if (fast) {
-            const int pl = 63 - __clzll(S.del0);
+            const int pl = 63 - __clzll(S.del[0]);
             const int jp = rbcast_i<SL>(R.ord, pl);
             const double xp = C.Ct[(size_t)(lane < MJ ? lane : 0) * C.N + jp];  // lane w: [A;G][w, jp] (used after the update)
             if (S.cDirty) fold_block_shift<SL>(L, R, S.K, pl, MJ, S.blkDz, xp);
             delete_var<SL>(L, R, S.K, pl, MJ, true, true, S.gz, xp);
-            S.del0 = S.del1 = 0ull;
+#pragma unroll
+            for (int t = 0; t < NSL; ++t) S.del[t] = 0ull;
             S.cDirty = false;
             S.blkDz = 0.0;
             WPH(10);  // deletes (update + downdate + compaction + shifts)
@@ -1703,28 +1821,21 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
             }
         } else {
         // highest row first: deleting row p leaves the rows below p in place
-        if (SL == 2) {
-            unsigned long long dm = S.del1;
+        sfor<0, SL>(SFOR_BODY(tr) {
+            SFOR_IDX(tr);
+            constexpr int t = SL - 1 - tr;
+            unsigned long long dm = S.del[t];
             while (dm) {
                 const int pl = 63 - __clzll(dm);
                 dm &= ~(1ull << pl);
-                const int jp = rbcast_i<SL>(R.ord, pl + KSLOT);
+                const int jp = rbcast_i<SL>(R.ord, pl + KSLOT * t);
                 const double xp = C.Ct[(size_t)(lane < MJ ? lane : 0) * C.N + jp];
-                delete_var<SL>(L, R, S.K, pl + KSLOT, MJ, single, false, S.gz, xp);
+                delete_var<SL>(L, R, S.K, pl + KSLOT * t, MJ, single, false, S.gz, xp);
             }
-        }
-        {
-            unsigned long long dm = S.del0;
-            while (dm) {
-                const int pl = 63 - __clzll(dm);
-                dm &= ~(1ull << pl);
-                const int jp = rbcast_i<SL>(R.ord, pl);
-                const double xp = C.Ct[(size_t)(lane < MJ ? lane : 0) * C.N + jp];
-                delete_var<SL>(L, R, S.K, pl, MJ, single, false, S.gz, xp);
-            }
-        }
+        });
         WPH(10);  // deletes (update + downdate + compaction + shifts)
-        S.del0 = S.del1 = 0ull;
+#pragma unroll
+        for (int t = 0; t < NSL; ++t) S.del[t] = 0ull;
         S.blkDz = 0.0;
         if (S.K > 0) {
             const unsigned cols = ((1u << MJ) - 1u) | (1u << CC);
@@ -1832,7 +1943,7 @@ __device__ __forceinline__ void slot1_reset(Rows &R) {  // the values every QP s
 
 // PARK: the build that keeps the second row slot in global scratch between the passes that need it.
 template <bool PARK>
-__device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, const WLds &L, double *gscr) {
+__device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, const WLds &L, double *gscr, double *park) {
     const int lane = lane_id();
     const int N = P.N, M = P.M, J = P.J, MJ = P.MJ;
     WCtx C;
@@ -1849,7 +1960,8 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     C.lamOut = P.lamOut ? P.lamOut + (size_t)prob * MJ : nullptr;
     C.gamOut = P.gamOut ? P.gamOut + (size_t)prob * N : nullptr;
     C.RC = P.waveRC;
-    C.iter = 0;
+    // hand-over from a build with a smaller factor (P.resume): continue from its (z, S) at its pass count
+    C.iter = P.resume ? P.fbIter[prob] : 0;
     C.ret = 0; C.det = SSQP_DETAIL_NONE;
     C.sBytes = 0; C.sRead = 0; C.sFlops = 0; C.sK3 = 0; C.maxK = 0;
 #ifdef SSQP_PHASE_PROFILE
@@ -1866,7 +1978,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     WState S;
     S.zg = P.z + (size_t)prob * N;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NSL; ++t) {
         S.R.ord[t] = 0; S.R.rank[t] = 0;
         S.R.zF[t] = S.R.ur[t] = S.R.dr[t] = 0.0;
         S.R.dg[t] = 1.0; S.R.rd[t] = 1.0;
@@ -1877,7 +1989,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
 #pragma unroll
     for (int m = 0; m < NCH; ++m) {
         const int r = 2 * lane + 128 * m;
-        if (r < N)
+        if (r < N && !P.resume)  // (resumed: z is the live copy the other build left)
             *reinterpret_cast<double2 *>(S.zg + r) = *reinterpret_cast<const double2 *>(P.x0 + (size_t)prob * N + r);
         const int s0 = (r < N) ? Sg[r] : SSQP_DN, s1 = (r < N) ? Sg[r + 1] : SSQP_DN;
         S.Sp |= ((unsigned)s0 & 15u) << (8 * m);
@@ -1894,13 +2006,13 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     S.hbValid = false;
     S.cDirty = false;
     S.nShift = 0;
-    S.del0 = S.del1 = 0ull;
+#pragma unroll
+    for (int t = 0; t < NSL; ++t) S.del[t] = 0ull;
     S.appJ = -1;
     S.relDz = 0.0;
     S.blkDz = 0.0;
     S.certMask = 0u;
     S.appAll = true;
-    double *park = gscr + WAVE_LS_DOUBLES + 128 * 64;
     if (PARK) slot1_store(S.R, park);
     for (int e = lane; e < NR * NR; e += 64) L.H[e] = 0.0;
     for (int e = lane; e < MJX * MJX; e += 64) L.GG[e] = 0.0;
@@ -1927,7 +2039,9 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
             S.cDirty = true;
         }
         // rows the pass will have: K - deletes + appends
-        int Knew = S.K - (__popcll(S.del0) + __popcll(S.del1)) + (S.appJ >= 0 ? 1 : 0);
+        int Knew = S.K + (S.appJ >= 0 ? 1 : 0);
+#pragma unroll
+        for (int t = 0; t < NSL; ++t) Knew -= __popcll(S.del[t]);
         if (S.appAll) {
             int nin = 0;
 #pragma unroll
@@ -1939,7 +2053,9 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
             handover = true;
             break;
         }
-        const bool two = (S.K > 63) || (Knew > 63);
+        const int Kmx = S.K > Knew ? S.K : Knew;
+        const bool two = Kmx > 63;           // more than one row slot
+        const bool four = NSL > 2 && Kmx > 127;  // ... more than two (the big-factor build)
         // PARK (the 256-register build): the second row slot is in registers only during a pass that has more than 63
         // rows -- under a tenth of the passes of the headline workload; between passes it is parked in the wavefront's
         // global scratch and the registers hold constants, so the one-slot passes are allocated as if it did not exist
@@ -1947,7 +2063,8 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
         int step = 0;  // 0: next pass, 1: done, 2: hand over
         do {
             int act;
-            if (two) act = wave_sync_factor<2>(C, L, S);
+            if (four) act = wave_sync_factor<NSL>(C, L, S);
+            else if (two) act = wave_sync_factor<2>(C, L, S);
             else act = wave_sync_factor<1>(C, L, S);
             if (act == W_BREAK) {
                 step = 1;
@@ -2006,7 +2123,8 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
                 break;  // (next pass)
             }
             if (K > C.maxK) C.maxK = K;
-            if (two) act = wave_pass<2>(C, L, S, gscr);
+            if (four) act = wave_pass<NSL>(C, L, S, gscr);
+            else if (two) act = wave_pass<2>(C, L, S, gscr);
             else act = wave_pass<1>(C, L, S, gscr);
             step = (act == W_BREAK) ? 1 : 0;
     
@@ -2046,7 +2164,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     if (lane < J) Sg[N + lane] = ((S.Emask >> lane) & 1u) ? SSQP_EO : SSQP_OE;
     wave_sync();
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NSL; ++t) {
         const int r = lane + KSLOT * t;
         if (r < S.K) zg[S.R.ord[t]] = S.R.zF[t];  // (a variable snapped by polishSz! carries its bound in zF already)
     }
@@ -2071,6 +2189,15 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
             st.sum_k3 = C.sK3;
             st.max_k = C.maxK;
             st.path = 1 | 4 | 16;  // LDS factor, kept-factor engine, wavefront kernel
+            if (P.resume) {  // add what the build that handed this QP over counted
+                const ssqp_stats s0 = P.stats[prob];
+                st.alg_bytes += s0.alg_bytes;
+                st.read_bytes += s0.read_bytes;
+                st.alg_flops += s0.alg_flops;
+                st.sum_k3 += s0.sum_k3;
+                st.max_k = st.max_k > s0.max_k ? st.max_k : s0.max_k;
+                st.path |= s0.path | 64;  // bit 6: continued in the big-factor build of the wavefront kernel
+            }
             P.stats[prob] = st;
         }
         if (handover) {
@@ -2085,7 +2212,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     wave_sync();
 }
 
-// Two builds of the kernel, one per translation unit (SSQP_WAVE_VARIANT) so that they compile side by side:
+// Three builds of the kernel, one per translation unit (SSQP_WAVE_VARIANT) so that they compile side by side:
 //   0: <1, false>  one wavefront per SIMD -- four QPs per CU, 512 registers, up to ~90 free variables, the whole
 //                  factor in LDS;
 //   1: <2, true>   two per SIMD -- eight QPs per CU, 256 registers, 20 KiB of LDS: rows >= 64 of the factor live in the
@@ -2093,21 +2220,31 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
 //                  (PARK).  Half of the QPs of the headline workload end with 64-79 free variables, but only in their
 //                  last tenth: carrying the second slot's 36 registers through every pass cost this build some 130
 //                  spilled registers and a tenth of its throughput.
-// Either hands a QP that outgrows it over to the workgroup kernel.
-template <int WPS, bool PARK>
+//   2: <1, false> with FOUR row slots (NSL = 4) -- the big-factor build: up to 255 free variables, rows >= 64 of the
+//                  factor in global scratch, back substitution by columns.  It takes the QPs builds 0 / 1 hand over
+//                  (P.resume: problem ids from their hand-over list, start from the (z, S) they left).
+// Each hands a QP that outgrows it over to the next stage (0 / 1 -> 2 -> the workgroup kernel).
+template <int WPS, bool PARK, int SLOTS>  // (SLOTS = NSL: part of the kernel's name, so that the builds' kernels differ)
 __global__ __launch_bounds__(64, WPS) void ssqp_wave_kernel(SolveParams P) {
+    static_assert(SLOTS == NSL, "one build per translation unit");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WLds L;
+    double *gscr = P.wscratch + (size_t)blockIdx.x * P.wscratchStride;
+    double *park = gscr;
     {
         double *d0 = reinterpret_cast<double *>(smem);
         const int rc = P.waveRC;
-        const int r1 = rc > 64 ? rc - 64 : 0;
         int o = 0;
         L.F.L0 = d0 + o; o += 2080;
-        if (PARK) {
-            L.F.L1 = P.wscratch + (size_t)blockIdx.x * P.wscratchStride + WAVE_LS_DOUBLES;
+        if (NSL > 2) {  // least-squares scratch for up to 256 rows, then rows 64..255 of up to 256 columns
+            L.F.L1 = gscr + WAVE_LS_DOUBLES_BIG;
+            L.F.R1 = 192;
+        } else if (PARK) {
+            L.F.L1 = gscr + WAVE_LS_DOUBLES;
             L.F.R1 = 64;
+            park = gscr + WAVE_LS_DOUBLES + 128 * 64;
         } else {
+            const int r1 = rc > 64 ? rc - 64 : 0;
             L.F.L1 = d0 + o; o += rc * r1 + 2;
             L.F.R1 = r1 > 0 ? r1 : 1;
         }
@@ -2119,29 +2256,36 @@ __global__ __launch_bounds__(64, WPS) void ssqp_wave_kernel(SolveParams P) {
         L.xn = d0 + o; o += 16;
         L.ra = reinterpret_cast<int16_t *>(d0 + o);
     }
-    double *gscr = P.wscratch + (size_t)blockIdx.x * P.wscratchStride;
     for (;;) {
         int prob = 0;
         if (threadIdx.x == 0) prob = (int)atomicAdd(P.queue, 1u);
         prob = __builtin_amdgcn_readfirstlane(prob);
-        if (prob >= P.nprob) break;
-        wave_solve_one<PARK>(P, prob, L, gscr);
+        if (P.resume) {  // the QPs another build handed over
+            if (prob >= (int)*P.resumeCount) break;
+            prob = P.resumeList[prob];
+        } else if (prob >= P.nprob) {
+            break;
+        }
+        wave_solve_one<PARK>(P, prob, L, gscr, park);
     }
 }
 
-#ifndef SSQP_WAVE_VARIANT
-#define SSQP_WAVE_VARIANT 0
-#endif
+}  // namespace
+
 #if SSQP_WAVE_VARIANT == 0
-#define WV_KERNEL ssqp_wave_kernel<1, false>
+#define WV_KERNEL ssqp_wave_kernel<1, false, 2>
 #define WV_LAUNCH launch_wave_v0
 #define WV_PHASES wave_phases_v0
 #elif SSQP_WAVE_VARIANT == 1
-#define WV_KERNEL ssqp_wave_kernel<2, true>
+#define WV_KERNEL ssqp_wave_kernel<2, true, 2>
 #define WV_LAUNCH launch_wave_v1
 #define WV_PHASES wave_phases_v1
+#elif SSQP_WAVE_VARIANT == 2
+#define WV_KERNEL ssqp_wave_kernel<1, false, 4>
+#define WV_LAUNCH launch_wave_v2
+#define WV_PHASES wave_phases_v2
 #else
-#error "SSQP_WAVE_VARIANT: 0 or 1"
+#error "SSQP_WAVE_VARIANT: 0, 1 or 2"
 #endif
 
 hipError_t WV_LAUNCH(const SolveParams &P, int grid, hipStream_t stream) {
@@ -2166,22 +2310,24 @@ int WV_PHASES(unsigned long long *out64, int reset) {  // adds this build's stam
 
 #if SSQP_WAVE_VARIANT == 0
 hipError_t launch_wave_v1(const SolveParams &P, int grid, hipStream_t stream);
+hipError_t launch_wave_v2(const SolveParams &P, int grid, hipStream_t stream);
 bool wave_kernel_applies(int N, int M, int J) {
     return (N % 2 == 0) && N >= 2 && N <= WAVE_MAXN && (M + J) <= WAVE_MJ;
 }
-int wave_lds_bytes(int rc) {  // rc <= 0: the eight-per-CU build (rows >= 64 in global scratch)
+int wave_lds_bytes(int rc) {  // rc <= 0: the builds that keep rows >= 64 in global scratch (eight-per-CU, big-factor)
     const int r1 = rc > 64 ? rc - 64 : 0;
     const int l1 = rc > 0 ? rc * r1 + 2 : 0;
     const int dbl = 2080 + l1 + NR * NR + 2 * (MJX * MJX + 1) + 16 * 3 + 8;
     return dbl * 8;
 }
-size_t wave_scratch_doubles(int N, int M, int J) {
-    (void)N; (void)M; (void)J;
+size_t wave_scratch_doubles(int variant) {
     // least-squares scratch, then (eight-per-CU build) rows 64..127 of up to 128 columns of the factor and the parked
-    // second row slot
+    // second row slot; (big-factor build) rows 64..255 of up to 256 columns
+    if (variant == 2) return (size_t)WAVE_LS_DOUBLES_BIG + 256 * 192 + 64;
     return (size_t)WAVE_LS_DOUBLES + 128 * 64 + PARK_FIELDS * 64 + 64;
 }
 hipError_t launch_solve_wave(const SolveParams &P, int grid, int variant, hipStream_t stream) {
+    if (variant == 2) return launch_wave_v2(P, grid, stream);
     if (variant == 1) return launch_wave_v1(P, grid, stream);
     return launch_wave_v0(P, grid, stream);
 }
@@ -2192,9 +2338,10 @@ hipError_t launch_solve_wave(const SolveParams &P, int grid, int variant, hipStr
 #if defined(SSQP_PHASE_PROFILE) && SSQP_WAVE_VARIANT == 0
 namespace ssqp {
 int wave_phases_v1(unsigned long long *out64, int reset);
+int wave_phases_v2(unsigned long long *out64, int reset);
 }
 extern "C" int ssqp_debug_wave_phases(unsigned long long *out64, int reset) {
     for (int k = 0; k < 64; ++k) out64[k] = 0;
-    return ssqp::wave_phases_v0(out64, reset) | ssqp::wave_phases_v1(out64, reset);
+    return ssqp::wave_phases_v0(out64, reset) | ssqp::wave_phases_v1(out64, reset) | ssqp::wave_phases_v2(out64, reset);
 }
 #endif

@@ -82,6 +82,15 @@ class Context:
         _capi.check(_capi.lib().ssqp_last_kernel_ms(self._h, C.byref(ms)), self._h)
         return ms.value
 
+    def recent_kernel_ms(self, n):
+        """durations (ms) of the solve kernels of the last n launches on this context, oldest first (n <= 16)"""
+        out = []
+        for back in range(n - 1, -1, -1):
+            ms = C.c_float(0)
+            _capi.check(_capi.lib().ssqp_recent_kernel_ms(self._h, back, C.byref(ms)), self._h)
+            out.append(ms.value)
+        return out
+
     def flush(self):
         """lazy_handover: issue what the last call still owes before its in/out buffers are reused"""
         _capi.check(_capi.lib().ssqp_flush(self._h), self._h)

@@ -82,10 +82,11 @@ def test_cfg3_n256_large_k_global_arena(pkg, orc):
     rel, stats = run_cfg(pkg, orc, pkg.CONFIGS["cfg3"], 8, opts=dict(wave_kernel=0))
     assert stats["max_k"].max() > 180
     assert ((stats["path"] & 8) != 0).all()
-    # default routing: the wavefront kernel starts every QP and hands it over when K outgrows its factor (bit 32)
+    # default routing: the wavefront kernel starts every QP and its big-factor build takes over when K outgrows the
+    # first build's factor (bit 64); nothing reaches the workgroup kernel (bit 32)
     rel, stats = run_cfg(pkg, orc, pkg.CONFIGS["cfg3"], 8, both=False)
     assert stats["max_k"].max() > 180
-    assert ((stats["path"] & 16) != 0).all() and ((stats["path"] & 32) != 0).all()
+    assert ((stats["path"] & 16) != 0).all() and ((stats["path"] & 64) != 0).all() and ((stats["path"] & 32) == 0).all()
     # from-scratch factorisation out of the global arena
     rel, stats = run_cfg(pkg, orc, pkg.CONFIGS["cfg3"], 2, opts=dict(incremental=0))
     assert ((stats["path"] & 2) != 0).all()
@@ -371,7 +372,7 @@ def test_free_set_beyond_256_rows(pkg, orc):
         assert ((stats["path"] & 2) != 0).all()                  # the global arena was used
         assert ((stats["path"] & 8) != 0).all()                  # ... after the kept factor had migrated there
         if not opts:
-            assert ((stats["path"] & 48) == 48).all()            # started in the wavefront kernel, handed over
+            assert ((stats["path"] & 112) == 112).all()          # wavefront kernel -> its big-factor build -> workgroup kernel
 
 
 def test_k0_start_n512_freeK(pkg, orc):
@@ -406,9 +407,13 @@ def test_cfg4_j0_family(pkg, orc):
 
 
 def test_cfg3_full_batch_1024(pkg, orc):
-    """BASELINE.json configs[2] at full size: 1024 x N=256, K up to ~230 (wavefront kernel -> hand-over)"""
-    rel, stats = run_cfg(pkg, orc, pkg.CONFIGS["cfg3"], 1024, both=False)
-    assert stats["max_k"].max() > 200
+    """BASELINE.json configs[2] at full size: 1024 x N=256, K up to ~230 (wavefront kernel -> its big-factor build), on
+    every start: four- and eight-per-CU first stage, and the big-factor build from the first pass"""
+    for opts in (None, dict(wave_qp_per_cu=8), dict(wave_kernel=2)):
+        rel, stats = run_cfg(pkg, orc, pkg.CONFIGS["cfg3"], 1024, both=False, opts=opts)
+        assert stats["max_k"].max() > 200
+        assert ((stats["path"] & 32) == 0).all()         # nothing needed the workgroup kernel
+        assert (((stats["path"] & 64) != 0).all()) == (not opts or "wave_kernel" not in opts)
 
 
 @pytest.mark.parametrize("N", [768, 601])
@@ -472,7 +477,7 @@ def test_second_row_slot_with_active_inequalities(pkg, orc, shape):
             if opts.get("wave_qp_per_cu") == 8:
                 assert ((stats["path"] & 48) == 16).all()    # the wavefront kernel to the end
             if opts.get("wave_qp_per_cu") == 4:
-                assert ((stats["path"] & 48) == 48).all()    # handed over beyond 92 rows
+                assert ((stats["path"] & 112) == 80).all()   # beyond 92 rows: continued in the big-factor build
         if shape == "boundary" and SEED_SHIFT == 0 and "wave_kernel" not in opts:
             assert (stats["max_k"] > 64).any() and ((stats["path"] & 32) == 0).all()
 
@@ -599,9 +604,10 @@ def test_host_buffer_chunked_and_resident_handle(pkg, orc):
 
 
 def test_lazy_handover_agrees_with_eager(pkg, orc):
-    """"lazy_handover": the workgroup-kernel launch on the wavefront kernel's hand-over list is issued by ssqp_sync /
-    the next call and only when the list is not empty.  cfg3 hands every QP over (K -> 229 > the wavefront kernel's
-    factor), cfg1 none: both must give the eager results, also with two contexts interleaved on two streams."""
+    """"lazy_handover": the launches on the wavefront kernel's hand-over list (big-factor build, then workgroup kernel)
+    are issued by ssqp_sync / the next call and only when the list is not empty.  cfg3 hands every QP over (K -> 229 >
+    the first build's factor), cfg1 none: both must give the eager results, also with two contexts interleaved on
+    two streams."""
     import torch
     for name, nprob in (("cfg3", 48), ("cfg1", 64)):
         cfg = pkg.CONFIGS[name]
@@ -623,7 +629,7 @@ def test_lazy_handover_agrees_with_eager(pkg, orc):
                 r = b.results()
             assert np.array_equal(r["S"], ref["S"]) and np.array_equal(r["status"], ref["status"])
             assert np.array_equal(r["z"], ref["z"])
-            assert ((r["stats"]["path"] & 32) != 0).all() == (name == "cfg3")
+            assert ((r["stats"]["path"] & 64) != 0).all() == (name == "cfg3")    # (cfg3: every QP is handed over)
         full = dict(prob)
         full["V"] = b0.t["V"].cpu().numpy()
         zo, So, sto, _, _ = oracle_batch(orc, full, S0, x0)

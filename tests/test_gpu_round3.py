@@ -178,3 +178,65 @@ def test_phase1_gpu_returns_on_poisoned_lp(pkg):
     st = st.cpu().numpy()
     assert st[0] == 1 and st[3] == 1           # the clean problems are untouched
     assert set(st[1:3].tolist()) <= {-1, 0, 1}
+
+
+# ---------------------------------------------------------------- the big-factor build of the wavefront kernel
+def _oracle_fast(orc, prob, S0, x0):
+    return orc.solveQP_warm_batch(prob["V"], prob["A"], prob["G"], prob["q"], prob["b"], prob["g"], prob["d"],
+                                  prob["u"], S0, x0, lapack=orc.lapack_available())
+
+
+@pytest.mark.parametrize("family", ["cfg3_like", "blocking", "inequalities", "n512"])
+def test_big_factor_build_families(pkg, orc, family):
+    """free sets of 128..250 rows in the four-row-slot build (rows >= 64 in global scratch, back substitution by
+    columns): appends only (cfg3), upper bounds that block at large K (deletes across the slot boundaries), active
+    inequalities at large K, N = 512.  Reached by hand-over from both first-stage builds and from the first pass."""
+    if family == "cfg3_like":       # K -> ~170, appends almost only
+        cfg, n = pkg.GenConfig(200, 1, 0, 400, 1e-3, 0.1, 1.2, 0.0), 24
+    elif family == "blocking":      # K -> ~215 with ~60 blocked steps on the way (deletes in every row slot)
+        cfg, n = pkg.GenConfig(256, 1, 0, 512, 1e-3, 2.5 / 256, 1.2, 0.0), 24
+    elif family == "inequalities":  # K -> ~195 with up to 10 active rows and ~40 blocked steps
+        cfg, n = pkg.GenConfig(224, 2, 8, 448, 1e-3, 4.0 / 224, 1.0, 0.0), 24
+    else:                           # N = 512: K -> ~180, ~90 blocked steps, up to 5 active rows
+        cfg, n = pkg.GenConfig(512, 1, 4, 1024, 1e-3, 8.0 / 512, 1.0, 0.01), 12
+    prob = pkg.generate_batch(cfg, n, 424242)
+    x0, S0, st = pkg.phase1_batch(prob)
+    ok = st == 1
+    assert ok.sum() >= n // 2
+    sub = {k: np.ascontiguousarray(v[ok]) for k, v in prob.items()}
+    zo, So, sto, _, _ = _oracle_fast(orc, sub, S0[ok], x0[ok])
+    assert (sto > 0).all()
+    ctx = pkg.default_context()
+    seen_big = False
+    for opts in (dict(), dict(wave_qp_per_cu=8), dict(wave_kernel=2)):
+        with ctx.options(**opts):
+            z, S, status, detail, stats = pkg.solveQP_batch(sub, S0[ok], x0[ok], want_stats=True)
+        assert_parity(z, S, status, zo, So, sto)
+        assert (stats["max_k"] > 127).any(), stats["max_k"]
+        big = (stats["max_k"] > 127) & (stats["max_k"] <= 252)
+        assert ((stats["path"][big] & 32) == 0).all()        # the workgroup kernel was not needed for those
+        seen_big = seen_big or bool(big.any())
+    assert seen_big
+
+
+def test_big_factor_build_trace_and_multipliers(pkg, orc):
+    """per-pass trace (K, W, kind, id) and the multipliers of the last pass through the hand-over chain"""
+    cfg = pkg.GenConfig(192, 1, 3, 384, 1e-3, 3.0 / 192, 1.0, 0.0)    # K -> ~160, up to 4 active rows, ~45 blocked steps
+    prob = pkg.generate_batch(cfg, 6, 424242)
+    x0, S0, st = pkg.phase1_batch(prob)
+    assert (st == 1).all()
+    zo, So, sto, _, _, lamo, gamo = orc.solveQP_warm_batch(prob["V"], prob["A"], prob["G"], prob["q"], prob["b"],
+                                                          prob["g"], prob["d"], prob["u"], S0, x0, want_mult=True)
+    db = pkg.DeviceBatch(prob, S0, x0, ntrace=1024).want_multipliers()
+    db.solve()
+    r = db.results()
+    assert_parity(r["z"], r["S"], r["status"], zo, So, sto)
+    assert (r["stats"]["max_k"] > 127).any()
+    _mult_close(r["lam"], r["gam"], lamo, gamo)
+    for p in range(6):
+        A = colmajor(prob["A"][p], cfg.M)
+        G = colmajor(prob["G"][p], cfg.J)
+        _, _, sto1, _, tr = orc.solveQP_warm(prob["V"][p], A, G, prob["q"][p], prob["b"][p], prob["g"][p],
+                                             prob["d"][p], prob["u"][p], S0[p], x0[p], max_trace=1024)
+        got = [tuple(int(v) for v in row) for row in r["trace"][p][:sto1]]
+        assert got == tr
