@@ -420,7 +420,7 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
         B.queue = qw + 4;
         B.wscratch = (double *)c->wscratchBig.p;
         B.wscratchStride = wstrideBig;
-        B.waveLdsBytes = ssqp::wave_lds_bytes(0);
+        B.waveLdsBytes = ssqp::wave_lds_bytes_big();
         B.waveRC = N < ssqp::WAVE_BIG_ROWS ? N : ssqp::WAVE_BIG_ROWS;
         B.resume = bigFirst ? 0 : 1;
         B.resumeCount = qw + 2;
@@ -532,7 +532,7 @@ int ssqp_solve_batch_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const doub
         return SSQP_ERR_ALLOC;
     if ((lambda && !ensure(c, c->hlam, P * (m + j) * 8)) || (gamma && !ensure(c, c->hgam, P * n * 8))) return SSQP_ERR_ALLOC;
     // (multipliers are written for status > 0 only: the buffers start from zero)
-    if (lambda && !hip_ok(c, hipMemsetAsync(c->hlam.p, 0, P * (m + j) * 8 + 8, c->stream), "hipMemsetAsync")) return SSQP_ERR_HIP;
+    if (lambda && (m + j) > 0 && !hip_ok(c, hipMemsetAsync(c->hlam.p, 0, P * (m + j) * 8, c->stream), "hipMemsetAsync")) return SSQP_ERR_HIP;
     if (gamma && !hip_ok(c, hipMemsetAsync(c->hgam.p, 0, P * n * 8, c->stream), "hipMemsetAsync")) return SSQP_ERR_HIP;
     // The upload of V (N*N*8 bytes per QP over PCIe) dwarfs the solve: the batch goes up in chunks, and every chunk is
     // solved on one of four launch lanes (child contexts) as soon as it has landed -- the solves run behind the

@@ -164,6 +164,7 @@ constexpr int WAVE_MJ = 11;      // constraint rows carried per free variable (M
 bool wave_kernel_applies(int N, int M, int J);
 // LDS bytes one wavefront needs for a kept factor of `rc` rows in LDS (rc <= 0: rows >= 64 in global scratch)
 int wave_lds_bytes(int rc);
+int wave_lds_bytes_big();  // LDS bytes of the big-factor build (kept factor rows < 64, Schur block, the column ring)
 // doubles of global scratch per wavefront of build `variant`
 size_t wave_scratch_doubles(int variant);
 constexpr int WAVE_BIG_ROWS = 252;  // row capacity of the big-factor build (four row slots of 64)

@@ -2,7 +2,7 @@
 (make -C statusswitchingqp.jl_amd/csrc prof); shares only, never quote its run time."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["SSQP_HIP_LIB"] = os.path.join(ROOT, "statusswitchingqp.jl_amd", "libssqp_hip_prof.so")
+os.environ["SSQP_HIP_LIB"] = os.environ.get("SSQP_PROF_LIB") or os.path.join(ROOT, "statusswitchingqp.jl_amd", "libssqp_hip_prof.so")
 sys.path.insert(0, ROOT)
 import numpy as np
 import __graft_entry__ as ge
@@ -13,6 +13,10 @@ cfg = pkg.CONFIGS[name]
 prob = pkg.generate_batch(cfg, nprob)
 x0, S0, st = pkg.phase1_batch(prob)
 db = pkg.DeviceBatch(prob, S0, x0)
+# optional context options as name=value (e.g. wave_kernel=2: start in the big-factor build, so every stamp is its own)
+for kv in sys.argv[3:]:
+    k, v = kv.split("=")
+    db.ctx.set_option(k, int(v))
 lib = pkg._capi.lib()
 lib.ssqp_debug_wave_phases.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 out = (C.c_ulonglong * 64)()
