@@ -68,6 +68,8 @@ constexpr int NSL = 4;
 #else
 constexpr int NSL = 2;
 #endif
+// only the big-factor build is ever launched on a hand-over list (P.resume): the other builds do not carry the code
+constexpr bool CAN_RESUME = NSL > 2;
 [[maybe_unused]] constexpr int WAVE_LS_DOUBLES = 128 * MJX + MJX * MJX + MJX + 21;  // global scratch of the purged-row least squares
 [[maybe_unused]] constexpr int WAVE_LS_DOUBLES_BIG = 256 * MJX + MJX * MJX + MJX + 21;  // ... of the big-factor build (up to 256 rows)
 constexpr double INF = __builtin_huge_val();
@@ -2263,7 +2265,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     C.gamOut = P.gamOut ? P.gamOut + (size_t)prob * N : nullptr;
     C.RC = P.waveRC;
     // hand-over from a build with a smaller factor (P.resume): continue from its (z, S) at its pass count
-    C.iter = P.resume ? P.fbIter[prob] : 0;
+    C.iter = (CAN_RESUME && P.resume) ? P.fbIter[prob] : 0;
     C.ret = 0; C.det = SSQP_DETAIL_NONE;
     C.sBytes = 0; C.sRead = 0; C.sFlops = 0; C.sK3 = 0; C.maxK = 0;
 #ifdef SSQP_PHASE_PROFILE
@@ -2291,7 +2293,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
 #pragma unroll
     for (int m = 0; m < NCH; ++m) {
         const int r = 2 * lane + 128 * m;
-        if (r < N && !P.resume)  // (resumed: z is the live copy the other build left)
+        if (r < N && !(CAN_RESUME && P.resume))  // (resumed: z is the live copy the other build left)
             *reinterpret_cast<double2 *>(S.zg + r) = *reinterpret_cast<const double2 *>(P.x0 + (size_t)prob * N + r);
         const int s0 = (r < N) ? Sg[r] : SSQP_DN, s1 = (r < N) ? Sg[r + 1] : SSQP_DN;
         S.Sp |= ((unsigned)s0 & 15u) << (8 * m);
@@ -2491,7 +2493,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
             st.sum_k3 = C.sK3;
             st.max_k = C.maxK;
             st.path = 1 | 4 | 16;  // LDS factor, kept-factor engine, wavefront kernel
-            if (P.resume) {  // add what the build that handed this QP over counted
+            if (CAN_RESUME && P.resume) {  // add what the build that handed this QP over counted
                 const ssqp_stats s0 = P.stats[prob];
                 st.alg_bytes += s0.alg_bytes;
                 st.read_bytes += s0.read_bytes;
@@ -2570,7 +2572,7 @@ __global__ __launch_bounds__(64, WPS) void ssqp_wave_kernel(SolveParams P) {
         int prob = 0;
         if (threadIdx.x == 0) prob = (int)atomicAdd(P.queue, 1u);
         prob = __builtin_amdgcn_readfirstlane(prob);
-        if (P.resume) {  // the QPs another build handed over
+        if (CAN_RESUME && P.resume) {  // the QPs another build handed over
             if (prob >= (int)*P.resumeCount) break;
             prob = P.resumeList[prob];
         } else if (prob >= P.nprob) {
