@@ -12,8 +12,9 @@
 // (the ratio test over the M0 basic rows, the pivot search of the LU, the sums over the nonbasic columns that sit
 // at a nonzero bound, taken from a compacted list).
 //
-// Workspace per QP in global memory (L2-resident: 119 KB at N = 512, M0 = 11): the LP matrix A1 (M0 x N1), Y (M0 x N1)
-// and the N1-vectors; LDS holds invB, the basis matrix being inverted and the M0-vectors.
+// Workspace per QP in global memory (76 KB at N = 512, M0 = 11): the LP matrix A1 (M0 x N1, row-major) and the
+// N1-vectors; the host's Y = invB * A[:, nonbasic] is never stored (see refreshY); LDS holds invB, the basis matrix
+// being inverted and the M0-vectors.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,19 +25,8 @@ namespace ssqp {
 namespace p1 {
 
 constexpr int NT1 = 256;
+constexpr int XB_CHUNK = 32;   // columns of the xb sum whose products are formed together (staged in LDS)
 constexpr double INF = __builtin_huge_val();
-
-struct Ws {  // per-QP global workspace, all of length N1 unless noted
-    double *A1, *Y;  // M0 x N1, ROW-major (entry (r, k) at r * N1 + k): a thread per column reads and writes coalesced
-    double *lo, *hi, *cost, *x, *colnorm, *range;
-    int32_t *S1;
-    int *nonbasic;   // 1 = nonbasic
-    int *list;       // compacted column list (N1)
-    int *freeVars;   // N
-    int *upperOnly;  // N
-};
-
-__device__ __forceinline__ size_t ws_doubles(int M0, int N1) { return (size_t)2 * M0 * N1 + 6 * (size_t)N1; }
 
 // ---- diagnostic build only (-DSSQP_PHASE_PROFILE): cycles per phase of the kernel, thread 0 of every workgroup ----
 #ifdef SSQP_PHASE_PROFILE
@@ -143,29 +133,42 @@ __device__ __forceinline__ bool invert_lu(double *a, double *x, int *piv, int n,
         }
         __syncthreads();
     }
-    // columns of the inverse: thread c solves L U x = P e_c with the host's loops
+    // columns of the inverse: L U x_c = P e_c for every column c with the host's operations per ELEMENT (x_c[i] takes its
+    // updates in the host's order k = 0 .. i - 1 forward, k = n - 1 .. i + 1 backward, then its division), but all the
+    // elements (c, i) a step touches are updated together: the host's "if (t != 0)" guard only skips subtractions of
+    // exact zeros, which change nothing.  P e_c: the host applies the row swaps to e_c in order; the permuted unit
+    // vector has its 1 where that sequence of swaps sends index c.
     for (int c = tid; c < n; c += NT1) {
-        double *xc = x + (size_t)c * n;
-        for (int i = 0; i < n; ++i) xc[i] = 0.0;
-        xc[c] = 1.0;
-        for (int k = 0; k < n; ++k)
-            if (piv[k] != k) {
-                const double t = xc[k];
-                xc[k] = xc[piv[k]];
-                xc[piv[k]] = t;
-            }
+        int pos = c;
         for (int k = 0; k < n; ++k) {
-            const double t = xc[k];
-            if (t != 0.0)
-                for (int i = k + 1; i < n; ++i) xc[i] -= a[(size_t)k * n + i] * t;
+            const int pk = piv[k];
+            if (pk != k) pos = (pos == k) ? pk : ((pos == pk) ? k : pos);
         }
-        for (int k = n - 1; k >= 0; --k) {
-            xc[k] /= a[(size_t)k * n + k];
-            const double t = xc[k];
-            for (int i = 0; i < k; ++i) xc[i] -= a[(size_t)k * n + i] * t;
-        }
+        piv[n + c] = pos;  // (second half of piv: scratch)
     }
     __syncthreads();
+    for (int e = tid; e < n * n; e += NT1) {
+        const int c = e / n, i = e - c * n;
+        x[e] = (piv[n + c] == i) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {  // forward: x_c[i] -= L(i, k) x_c[k]  for i > k
+        const int w = n - k - 1;
+        for (int e = tid; e < n * w; e += NT1) {
+            const int c = e / w, i = k + 1 + (e - c * w);
+            x[(size_t)c * n + i] -= a[(size_t)k * n + i] * x[(size_t)c * n + k];
+        }
+        __syncthreads();
+    }
+    for (int k = n - 1; k >= 0; --k) {  // backward: x_c[k] /= U(k, k), then x_c[i] -= U(i, k) x_c[k]  for i < k
+        for (int c = tid; c < n; c += NT1) x[(size_t)c * n + k] /= a[(size_t)k * n + k];
+        __syncthreads();
+        for (int e = tid; e < n * k; e += NT1) {
+            const int c = e / k, i = e - c * k;
+            x[(size_t)c * n + i] -= a[(size_t)k * n + i] * x[(size_t)c * n + k];
+        }
+        __syncthreads();
+    }
     for (int e = tid; e < n * n; e += NT1) a[e] = x[e];
     __syncthreads();
     return true;
@@ -182,6 +185,7 @@ struct P1Params {
     size_t wsStride;
     int *wsInt;        // nprob integer workspaces of wsIntStride ints
     size_t wsIntStride;
+    int ldsVec;        // 1: the N1-vectors every pass reads (S1, nonbasic, x, colnorm, sdot) live in LDS (they fit)
 };
 
 __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (four workgroups per CU: 1,024 QPs resident)
@@ -210,9 +214,10 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
     double *acc = pv + M0;
     double *blo = acc + M0, *bhi = blo + M0;       // bounds of the basic variables by row
     double *redv = bhi + M0;                       // 4
-    int *basis = reinterpret_cast<int *>(redv + 4);  // M0
-    int *piv = basis + M0;                         // M0
-    int *redi = piv + M0;                          // 4
+    double *terms = redv + 4;                      // XB_CHUNK x M0: products Y[r, k] x[k] of the xb sum, a chunk of columns at a time
+    int *basis = reinterpret_cast<int *>(terms + (size_t)XB_CHUNK * M0);  // M0
+    int *piv = basis + M0;                         // 2 M0 (row swaps of the LU, then the positions of the permuted unit vectors)
+    int *redi = piv + 2 * M0;                      // 4
     int *misc = redi + 4;                          // [0] count, [1] flag, [2] action, [3] leaveStatus, [4] n free, [5] n upperOnly
 
     // ---- free / upper-only variables (SSQP.jl:484-509), ascending lists
@@ -226,9 +231,22 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
     int *list = nonbasic + N1;
     double *wd = P.ws + (size_t)prob * P.wsStride;
     double *A1 = wd;
-    double *Y = A1 + (size_t)M0 * N1;
-    double *lo = Y + (size_t)M0 * N1;
+    double *lo = A1 + (size_t)M0 * N1;
+    // M0: sign of the artificial column of every row (behind the integers, 8-byte aligned)
+    double *sgnArt = reinterpret_cast<double *>((reinterpret_cast<size_t>(misc + 8) + 7) & ~(size_t)7);
     double *hi = lo + N1, *cost = hi + N1, *x = cost + N1, *colnorm = x + N1, *range = colnorm + N1;
+    double *sdot = range + N1;   // per nonbasic column: Y[:,k] . c[basis] of the current basis (formed with Y, read by the pricing)
+    if (P.ldsVec) {
+        // the vectors every simplex pass sweeps (pricing, column lists) in LDS instead of the global workspace: a pass is
+        // then free of dependent global round trips apart from the entering column
+        const int N1x = 2 * N + J + M0;  // (largest N1: every variable free)
+        double *dv = sgnArt + M0;
+        x = dv;
+        colnorm = dv + N1x;
+        sdot = dv + 2 * (size_t)N1x;
+        S1 = reinterpret_cast<int32_t *>(dv + 3 * (size_t)N1x);
+        nonbasic = S1 + N1x;
+    }
 
     // ---- the LP of initQP: A1 = [A; G | slack | -free copies | artificials]
     for (size_t e = tid; e < (size_t)M0 * N1; e += NT1) A1[e] = 0.0;
@@ -277,6 +295,7 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
     __syncthreads();
     for (int j = tid; j < M0; j += NT1) {
         const double sgn = rhs[j] >= acc[j] ? 1.0 : -1.0;
+        sgnArt[j] = sgn;
         invB[(size_t)j * M0 + j] = sgn;
         A1[(size_t)(j) * N1 + (N0 + j)] = sgn;
         xb[j] = fabs(acc[j] - rhs[j]);
@@ -299,10 +318,33 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
     // (the column of A1 / of Y a thread works on is pulled into registers first when M0 <= 16: the sums below are
     //  sequential by construction, and with a dependent global load per term each term would cost a cache round trip)
     constexpr int MC = 16;
-    auto refreshY = [&]() {  // Y[:,k] = invB * A1[:,k] for the nonbasic columns
+    // The host keeps Y = invB * A[:, nonbasic] (Simplex.jl:595) and reads it in two places: the pricing (Y[:,k] . c[basis])
+    // and the xb sum (Y[:,k] x_k of the nonbasic columns at a nonzero bound).  Here Y[:,k] only ever exists in the
+    // registers of the thread that owns column k: the pricing's dot product is formed at once (same order r = 0 .. M0 - 1
+    // as the host's price()) and stored -- one number per column instead of M0 written and read back -- and the few
+    // columns the xb sum needs are formed again where it needs them (same sums, same order: same bits).
+    auto refreshY = [&]() {
+        if (tid < M0) acc[tid] = basis[tid] >= N0 ? 1.0 : 0.0;  // c[basis] (LDS: broadcast reads below)
+        __syncthreads();
+        // slack and artificial columns are (signed) unit vectors: (invB * a)_r is the sum's single nonzero term -- the same
+        // bits as the sum (its other terms are products with 0.0 and leave the value, or +0.0, as it is)
+        for (int e = tid; e < J + M0; e += NT1) {
+            const int k = e < J ? N + e : N0 + (e - J);
+            if (!nonbasic[k]) continue;
+            const int row = e < J ? M + e : e - J;
+            const double val = e < J ? 1.0 : sgnArt[row];
+            double sd = 0.0;
+            for (int r = 0; r < M0; ++r) {
+                const double sr = 0.0 + invB[(size_t)row * M0 + r] * val;
+                sd += sr * acc[r];
+            }
+            sdot[k] = sd;
+        }
         for (int k = tid; k < N1; k += NT1) {
+            if (k >= N && (k < N + J || k >= N0)) continue;  // (unit columns: done above)
             if (!nonbasic[k]) continue;
             const double *ak = A1 + k;  // (entry t of column k: ak[t * N1])
+            double sd = 0.0;
             if (M0 <= MC) {
                 double av[MC];
 #pragma unroll
@@ -312,15 +354,24 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
 #pragma unroll
                     for (int t = 0; t < MC; ++t)
                         if (t < M0) s += invB[(size_t)t * M0 + r] * av[t];
-                    Y[(size_t)(r) * N1 + k] = s;
+                    sd += s * acc[r];
                 }
             } else {
-                for (int r = 0; r < M0; ++r) {
-                    double s = 0.0;
-                    for (int t = 0; t < M0; ++t) s += invB[(size_t)t * M0 + r] * ak[(size_t)t * N1];
-                    Y[(size_t)(r) * N1 + k] = s;
+                // (four rows at a time: the four sums are independent chains, each in the host's order over t)
+                for (int r0 = 0; r0 < M0; r0 += 4) {
+                    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+                    for (int t = 0; t < M0; ++t) {
+                        const double at = ak[(size_t)t * N1];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (r0 + u < M0) s4[u] += invB[(size_t)t * M0 + r0 + u] * at;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (r0 + u < M0) sd += s4[u] * acc[r0 + u];
                 }
             }
+            sdot[k] = sd;
         }
         __syncthreads();
     };
@@ -342,32 +393,14 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
         const bool bland = loop > N1;
         double best = -INF;
         int bidx = 0x7fffffff;
-        if (tid < M0) acc[tid] = cost[basis[tid]];  // c[basis] (LDS: broadcast reads below)
-        __syncthreads();
         for (int k = tid; k < N1; k += NT1) {
-            double s = 0.0;
-            int sk;
-            double ck, nk;
-            if (M0 <= MC) {
-                // (everything the column needs is requested at once, basic or not: one memory round trip per column)
-                double yv[MC];
-                const int nb = nonbasic[k];
-                sk = S1[k];
-                ck = cost[k];
-                nk = colnorm[k];
-#pragma unroll
-                for (int r = 0; r < MC; ++r) yv[r] = (r < M0) ? Y[(size_t)(r) * N1 + k] : 0.0;
-                if (!nb) continue;
-#pragma unroll
-                for (int r = 0; r < MC; ++r)
-                    if (r < M0) s += yv[r] * acc[r];
-            } else {
-                if (!nonbasic[k]) continue;
-                for (int r = 0; r < M0; ++r) s += Y[(size_t)(r) * N1 + k] * acc[r];
-                sk = S1[k];
-                ck = cost[k];
-                nk = colnorm[k];
-            }
+            // (everything the column needs is requested at once, basic or not: one memory round trip per column)
+            const int nb = nonbasic[k];
+            const int sk = S1[k];
+            const double ck = k >= N0 ? 1.0 : 0.0;  // (= cost[k]: the Phase-1 objective is the sum of the artificials)
+            const double nk = colnorm[k];
+            const double s = sdot[k];
+            if (!nb) continue;
             double hv = ck - s;
             if (sk == SSQP_DN) hv = -hv;
             if (hv > tol) {
@@ -481,22 +514,25 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
         // xb = invB*b - Y*x[nonbasic]: the nonbasic columns at a nonzero value, ascending
         {
             const int cnt = compact_columns(N1, list, &misc[0], [&](int kk) { return nonbasic[kk] && x[kk] != 0.0; });
-            for (int r = tid; r < M0; r += NT1) {
-                double a2 = 0.0;
-                for (int t0 = 0; t0 < cnt; t0 += 4) {  // four terms' loads in flight, summed in the host's order
-                    int kk[4];
-                    double yv[4], xv[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) kk[e] = list[t0 + e < cnt ? t0 + e : t0];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        yv[e] = Y[(size_t)(r) * N1 + kk[e]];
-                        xv[e] = x[kk[e]];
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (t0 + e < cnt) a2 += yv[e] * xv[e];
+            // the sum runs over the listed columns in ascending order, one rounded multiply and one rounded add per term
+            // (the host's order): the PRODUCTS of a chunk of columns are formed by all threads at once (one memory round
+            // trip for the chunk instead of one per term), the adds stay in order
+            double a2 = 0.0;
+            for (int t0 = 0; t0 < cnt; t0 += XB_CHUNK) {
+                const int nt = cnt - t0 < XB_CHUNK ? cnt - t0 : XB_CHUNK;
+                for (int e = tid; e < nt * M0; e += NT1) {
+                    const int t = e / M0, r = e - t * M0;
+                    const int kk = list[t0 + t];
+                    double y = 0.0;  // Y[r, kk] = (invB * A1[:, kk])_r, as refreshY forms it
+                    for (int t2 = 0; t2 < M0; ++t2) y += invB[(size_t)t2 * M0 + r] * A1[(size_t)t2 * N1 + kk];
+                    terms[(size_t)t * M0 + r] = y * x[kk];
                 }
+                __syncthreads();
+                if (tid < M0)
+                    for (int t = 0; t < nt; ++t) a2 += terms[(size_t)t * M0 + tid];
+                __syncthreads();
+            }
+            for (int r = tid; r < M0; r += NT1) {
                 double s = 0.0;
                 for (int t = 0; t < M0; ++t) s += invB[(size_t)t * M0 + r] * rhs[t];
                 xb[r] = s - a2;
@@ -539,15 +575,20 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
 
 size_t phase1_ws_doubles(int N, int M, int J) {
     const int M0 = M + J, N1 = 2 * N + J + M0;  // (every variable free: n = N)
-    return (size_t)2 * M0 * N1 + 6 * (size_t)N1 + 8;
+    return (size_t)M0 * N1 + 7 * (size_t)N1 + 8;
 }
 size_t phase1_ws_ints(int N, int M, int J) {
     const int M0 = M + J, N1 = 2 * N + J + M0;
     return (size_t)2 * N + 3 * (size_t)N1 + 8;
 }
-size_t phase1_lds_bytes(int M, int J) {
+size_t phase1_lds_bytes(int M, int J) {  // without the N1-vectors
     const size_t M0 = (size_t)(M + J);
-    return (2 * M0 * M0 + 6 * M0 + 4) * 8 + (2 * M0 + 4 + 8) * 4 + 64;
+    return (2 * M0 * M0 + 7 * M0 + 4 + p1::XB_CHUNK * M0) * 8 + (3 * M0 + 4 + 8) * 4 + 64;
+}
+// with x, colnorm, sdot, S1, nonbasic of up to N1x = 2N + J + M0 columns in LDS
+static size_t phase1_lds_bytes_vec(int N, int M, int J) {
+    const size_t N1x = (size_t)2 * N + J + M + J;
+    return phase1_lds_bytes(M, J) + N1x * (3 * 8 + 2 * 4) + 16;
 }
 hipError_t launch_phase1(int nprob, int N, int M, int J, const double *A, const double *G, const double *b, const double *g,
                          const double *d, const double *u, double tol, double *x0, int32_t *S, int32_t *status, double *ws,
@@ -558,7 +599,13 @@ hipError_t launch_phase1(int nprob, int N, int M, int J, const double *A, const 
     P.tol = tol;
     P.x0 = x0; P.S = S; P.status = status;
     P.ws = ws; P.wsStride = wsStride; P.wsInt = wsInt; P.wsIntStride = wsIntStride;
-    const size_t lds = phase1_lds_bytes(M, J);
+    // four workgroups per CU keep 1,024 QPs resident: the N1-vectors go to LDS when they fit in a quarter of it
+    size_t lds = phase1_lds_bytes(M, J);
+    P.ldsVec = 0;
+    if (phase1_lds_bytes_vec(N, M, J) <= (size_t)LDS_BYTES / 4) {
+        P.ldsVec = 1;
+        lds = phase1_lds_bytes_vec(N, M, J);
+    }
     static unsigned long long ldsSet = 0ull;
     hipError_t e = allow_full_lds(reinterpret_cast<const void *>(&p1::ssqp_phase1_kernel), &ldsSet);
     if (e != hipSuccess) return e;

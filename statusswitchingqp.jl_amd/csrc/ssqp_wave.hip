@@ -1239,6 +1239,7 @@ __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int 
     gg_rank1(L, 1.0);
     wave_sync();
     C.sRead += 64ll * K + 64ll * MJ + 16;
+    if (NSL > 2 && SL >= 2 && K > 64) C.sRead += 8ll * ((long long)(K - 64) * 64 + (long long)(K - 64) * (K - 65) / 2);
     K += 1;
     return true;
 }
@@ -1681,6 +1682,8 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
     if (NSL > 2 && SL >= 2) {  // (rows >= 64 in global memory: by columns, streamed through the ring)
         if (K <= 192) back_sweep_cols<SL, 1>(L, K, v);
         else back_sweep_cols<SL, 2>(L, K, v);
+        // (the factor's global part, rows max(64, c + 1) .. K - 1 of every column: read once here, once by the append)
+        C.sRead += 8ll * ((long long)(K - 64) * 64 + (long long)(K - 64) * (K - 65) / 2);
     } else {
         back_sweep<SL>(L.F, K, v);
     }

@@ -2,7 +2,7 @@
 (make -C statusswitchingqp.jl_amd/csrc prof); shares only, never quote its run time."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["SSQP_HIP_LIB"] = os.path.join(ROOT, "statusswitchingqp.jl_amd", "libssqp_hip_prof.so")
+os.environ["SSQP_HIP_LIB"] = os.environ.get("SSQP_PROF_LIB") or os.path.join(ROOT, "statusswitchingqp.jl_amd", "libssqp_hip_prof.so")
 sys.path.insert(0, ROOT)
 import numpy as np
 import __graft_entry__ as ge

@@ -20,7 +20,9 @@ def per_launch(passdir, only=None):
             if only is not None and only not in kn:
                 continue
             if "ssqp_solve_kernel" in kn or "ssqp_wave_kernel" in kn:
-                acc[r["Counter_Name"]]["wave" if "wave" in kn else "wg"].append(float(r["Counter_Value"]))
+                # one class per kernel of the hand-over chain (each is launched once per batch, possibly on an empty list)
+                cls = kn.split("(ssqp::SolveParams")[0].split("ssqp_")[-1]
+                acc[r["Counter_Name"]][cls].append(float(r["Counter_Value"]))
     out = {}
     for c, d in acc.items():
         out[c] = sum(sum(v) / len(v) for v in d.values())
@@ -48,5 +50,15 @@ w8 = per_launch("pmc_write_lanes", "ssqp_wave_kernel<2, true, 2>").get("WRITE_SI
 if f8 is not None and w8 is not None:
     res["eight_per_cu_build"] = {"FETCH_SIZE_KiB": f8, "WRITE_SIZE_KiB": w8, "hbm_bytes_per_launch": (2.0 * f8 + w8) * 1024.0,
                                  "sq": per_launch("pmc_sq1_lanes", "ssqp_wave_kernel<2, true, 2>")}
+# cfg3 (big-factor build): written beside, keyed the same way (bench.py --config cfg3 --pmc-json <that file>)
+f3 = per_launch("pmc_fetch_cfg3").get("FETCH_SIZE")
+w3 = per_launch("pmc_write_cfg3").get("WRITE_SIZE")
+if f3 is not None and w3 is not None:
+    res3 = {"config": "cfg3", "nprob": 1024, "tag": tag, "kernel_source_sha256": bench.kernel_source_hash(),
+            "correction": res["correction"],
+            "default_formulation": {"FETCH_SIZE_KiB": f3, "WRITE_SIZE_KiB": w3, "hbm_bytes_per_launch": (2.0 * f3 + w3) * 1024.0,
+                                    "sq": per_launch("pmc_sq1_cfg3")}}
+    json.dump(res3, open(os.path.join(base, "pmc_counters_cfg3.json"), "w"), indent=1)
+    print(json.dumps(res3, indent=1))
 json.dump(res, open(os.path.join(base, "pmc_counters.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
