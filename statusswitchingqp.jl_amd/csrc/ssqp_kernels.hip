@@ -1698,7 +1698,7 @@ struct ProbCtx {
     const double *__restrict__ uhi;
     ssqp_trace *trace;
     int ntrace;
-    double *lamOut, *gamOut;  // this problem's multiplier outputs (null: not requested)
+    bool wantMult;    // multiplier outputs were asked for: the last pass leaves what solve_one needs in LDS
     int arenaCap;
     bool dense;       // read zero-weight columns too (roofline measurement of the dense formulation)
     double *garena;
@@ -2672,7 +2672,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
                 __syncthreads();
             }
             if (tid == 0 && Lda < -tolG) ev = keymin(ev, KeyMin{Lda, N + (int)L.rowsE[wrow] - M});
-            if (tid == 0 && posk < 0 && C.lamOut) C.lamOut[L.rowsE[wrow]] = Lda;  // (a purged row: as KKTchk! computes it)
+            if (tid == 0 && posk < 0 && C.wantMult) L.lin[L.rowsE[wrow]] = Lda;  // (a purged row, as KKTchk! computes it; `lin` is idle here)
         }
     }
     ev = block_keymin(ev, L);
@@ -2693,8 +2693,11 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
         __syncthreads();
         return ACT_CONTINUE;
     }
-    // ---- optimal: the multipliers of this pass leave the kernel when asked for (alphaL SSQP.jl:351, gamma :352)
-    if (C.lamOut) {
+    // ---- optimal: when the multipliers of this pass were asked for (alphaL SSQP.jl:351, gamma :352), complete their
+    // images in LDS -- `lin` = lambda by row id (purged active inequalities were stored above), `gam` = gamma by variable;
+    // solve_one writes them out (it holds the output pointers; carrying them through this function costs registers in
+    // every instantiation)
+    if (C.wantMult) {
         for (int r = tid; r < MJ; r += NT) {
             int posA = -1;  // position among the active rows
             for (int w = 0; w < W0; ++w)
@@ -2706,12 +2709,9 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
                     for (int w = 0; w < W; ++w)
                         if (L.ra[w] == posA) posk = w;
             }
-            if (posk >= 0) C.lamOut[r] = L.aL[posk];
-            else if (posA < 0 || r < M) C.lamOut[r] = 0.0;  // inactive, or a purged equality row (no value in the reference)
-            // (a purged active inequality keeps the value written above)
+            if (posk >= 0) L.lin[r] = L.aL[posk];
+            else if (posA < 0 || r < M) L.lin[r] = 0.0;  // inactive, or a purged equality row (no value in the reference)
         }
-    }
-    if (C.gamOut) {
         for (int i = tid; i < N; i += NT) {
             double gmm = 0.0;
             if (L.pos[i] < 0) {
@@ -2722,7 +2722,7 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
                     gmm = (gmm + q[i]) + s3;
                 }
             }
-            C.gamOut[i] = gmm;
+            L.gam[i] = gmm;
         }
     }
     // ---- polishSz!  SSQP.jl:10-32 ----
@@ -2771,8 +2771,7 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
     C.uhi = P.u + (size_t)prob * P.su;
     C.trace = P.trace ? P.trace + (size_t)prob * P.ntrace : nullptr;
     C.ntrace = P.ntrace;
-    C.lamOut = P.lamOut ? P.lamOut + (size_t)prob * P.MJ : nullptr;
-    C.gamOut = P.gamOut ? P.gamOut + (size_t)prob * N : nullptr;
+    C.wantMult = P.lamOut != nullptr || P.gamOut != nullptr;
     C.arenaCap = P.arenaCap;
     C.dense = P.denseGamma != 0;
     C.garena = garena;
@@ -2871,10 +2870,10 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
             if (done) {
                 if (trace && tid == 0) *trace = ssqp_trace{0, 0, 3, 0};
                 // (no multipliers exist on this exit of the reference: gamma = V z + q, what freeK! tested; lambda = 0)
-                if (C.lamOut)
-                    for (int r = tid; r < P.MJ; r += NT) C.lamOut[r] = 0.0;
-                if (C.gamOut)
-                    for (int i = tid; i < N; i += NT) C.gamOut[i] = L.gam[i] + C.q[i];
+                if (C.wantMult) {
+                    for (int r = tid; r < P.MJ; r += NT) L.lin[r] = 0.0;
+                    for (int i = tid; i < N; i += NT) L.gam[i] = L.gam[i] + C.q[i];
+                }
                 C.ret = C.iter;  // SSQP.jl:281 (no polishSz! on this exit)
                 break;
             }
@@ -2954,6 +2953,12 @@ __device__ __forceinline__ void solve_one(const SolveParams &P, int prob, const 
     }
     __syncthreads();
     PHASE(C, 11);
+    if (C.wantMult && C.ret > 0) {  // the last pass left lambda (by row id) in `lin` and gamma (by variable) in `gam`
+        if (P.lamOut)
+            for (int r = tid; r < P.MJ; r += NT) P.lamOut[(size_t)prob * P.MJ + r] = L.lin[r];
+        if (P.gamOut)
+            for (int i = tid; i < N; i += NT) P.gamOut[(size_t)prob * N + i] = L.gam[i];
+    }
     for (int i = tid; i < N; i += NT) P.z[(size_t)prob * N + i] = L.z[i];
     for (int i = tid; i < N + J; i += NT) Sg[i] = L.S[i];
     if (tid == 0) {

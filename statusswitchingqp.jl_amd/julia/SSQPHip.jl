@@ -150,6 +150,29 @@ function solveQP_batch(Qs::Vector{QP{Float64}}, Ss::Vector{Vector{Status}}, x0s:
 end
 
 """
+    solveQP_multipliers(Q::QP{Float64}, S, x0; settings) -> (z, S, status, lambda, gamma)
+
+`solveQP(Q, S, x0)` that also returns the Lagrange multipliers of the last pass, which the reference computes inside the
+loop (`alphaL`, `gamma`, SSQP.jl:351-352; purged rows SSQP.jl:158-159) and never returns: `lambda` by row of `[A; G]`
+(length M+J), `gamma` by variable (length N, 0 on the free ones).  One `ccall` of `ssqp_solve_batch_f64` with one problem.
+"""
+function solveQP_multipliers(Q::QP{Float64}, S::Vector{Status}, x0::Vector{Float64}; settings=Settings{Float64}())
+    z = Vector{Float64}(undef, Q.N); status = Ref{Int64}(0); detail = Ref{Int32}(0)
+    lambda = zeros(Q.M + Q.J); gamma = zeros(Q.N)
+    cs = Ref(CSettings(settings.maxIter, 0, settings.tol, settings.tolG))
+    Si = reinterpret(Int32, S)
+    GC.@preserve S begin
+        check(ccall((:ssqp_solve_batch_f64, libssqp), Cint,
+            (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+             Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ref{CSettings},
+             Ref{Int64}, Ref{Int32}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
+            ctx(), 1, Q.N, Q.M, Q.J, Q.V, Q.A, Q.G, Q.q, Q.b, Q.g, Q.d, Q.u, Si, x0, z, cs, status, detail, C_NULL,
+            lambda, gamma))
+    end
+    return z, S, Int(status[]), lambda, gamma
+end
+
+"""
     use_moi_qp_status!()
 
 DELIBERATE DEVIATION, opt-in.  `MOI.get(::Optimizer, ::MOI.TerminationStatus)` of the reference maps `Results[3]`

@@ -529,7 +529,7 @@ def _phase1_gpu(pkg, prob):
     return db.x0.cpu().numpy(), db.S0.cpu().numpy(), st.cpu().numpy()
 
 
-@pytest.mark.parametrize("name,nprob", [("cfg1", 32), ("cfg2", 8), ("cfg4", 256), ("cfg3", 64)])
+@pytest.mark.parametrize("name,nprob", [("cfg1", 32), ("cfg2", 8), ("cfg4", 256), ("cfg3", 64), ("cfg5", 1)])
 def test_phase1_gpu_bit_identical_to_host(pkg, orc, name, nprob):
     """initQP + cDantzigLP (SSQP.jl:461-560, Simplex.jl:445-615) on the GPU: the vertex (x0, S0) and the status are
     bit for bit those of the host C++ stage and of the oracle -- so the loop that follows runs the same passes"""
