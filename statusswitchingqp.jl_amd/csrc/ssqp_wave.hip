@@ -376,7 +376,7 @@ __device__ __forceinline__ void wait_all_landed() {
 }
 
 // N contiguous doubles (a column of V, a row of Ct) into slot `slot`: piece m = elements 128 m + 2 lane, + 1.
-// Lane 0 of every piece always loads (the counted waits rely on exactly NI instructions per slot).
+// Every slot takes exactly NI DMA instructions whatever N is (the counted waits rely on it).
 template <int NI>
 __device__ __forceinline__ void ring_issue_dense(const WLds &L, int slot, const double *__restrict__ col, int N) {
     const int lane = lane_id();
@@ -384,7 +384,7 @@ __device__ __forceinline__ void ring_issue_dense(const WLds &L, int slot, const 
     for (int m = 0; m < NI; ++m) {
         const int e = 128 * m + 2 * lane;
         const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(L.ringAddr + (unsigned)(slot * NI + m) * 1024u));
-        if (e < N || lane == 0) glds16(col + (e < N ? e : 0), dst);
+        glds16(col + (e < N ? e : 0), dst);  // (every lane loads: lanes beyond N re-read element 0 -- no exec juggling per DMA)
     }
 }
 // the part of column c of the factor that lives in global memory (rows 64 .. K - 1, only rows > c) into slot `slot`:
@@ -398,7 +398,9 @@ __device__ __forceinline__ void ring_issue_faccol(const WLds &L, int slot, int c
         const int r = 64 + 128 * m + 2 * lane;  // this lane's two rows: r, r + 1
         const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(L.ringAddr + (unsigned)(slot * NI + m) * 1024u));
         const bool need = (r + 1 > c) && (r < K);
-        if (need || lane == 0) glds16(src + (need ? r - 64 : 128 * m), dst);
+        // (every lane loads: the lanes whose rows are not needed re-read the piece's first 16 bytes -- one sector more per
+        //  instruction, no exec juggling; the reader masks by row)
+        glds16(src + (need ? r - 64 : 128 * m), dst);
     }
 }
 
@@ -526,13 +528,21 @@ __device__ __forceinline__ void fwd_sweep_ring(const WLds &L, int Kin, double (&
 #pragma unroll
             for (int u = 0; u < 4; ++u) ring_read_faccol<SL, NI>(L, K, c0 + 4 + u, ln[u]);
         }
+        {   // (64 is a multiple of 4: the four columns' rows sit in ONE slot -- picked once per group, not per broadcast)
+            const int tb = c0 >> 6, l0 = c0 & 63;
+            sfor<0, SL>(SFOR_BODY(tq) {
+                SFOR_IDX(tq);
+                if (tb == tq) {  // uniform
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (c0 + u < K) {  // uniform
-                const double yc = rbcast<SL>(y, c0 + u);
+                    for (int u = 0; u < 4; ++u) {
+                        if (c0 + u < K) {  // uniform
+                            const double yc = readlane_f64(y[tq], l0 + u);
 #pragma unroll
-                for (int t = 0; t < SL; ++t) y[t] = fma(-lc[u][t], yc, y[t]);
-            }
+                            for (int t = tq; t < SL; ++t) y[t] = fma(-lc[u][t], yc, y[t]);  // (slots above hold rows <= c: zeros)
+                        }
+                    }
+                }
+            });
         }
         wait_lds();  // (ln has arrived: the slots of group g + 1 are free for the next round's request)
 #pragma unroll
@@ -2568,7 +2578,9 @@ __global__ __launch_bounds__(64, WPS) void ssqp_wave_kernel(SolveParams P) {
         if (NSL > 2) {
             o = (o + 127) / 128 * 128;  // (1 KiB alignment of the DMA pieces)
             L.ring = d0 + o;
-            L.ringAddr = (unsigned)(size_t)(d0 + o);  // low half of the flat address of an LDS location = its LDS byte address
+            // low half of the flat address of an LDS location = its LDS byte address; read through v_readfirstlane so that
+            // the compiler keeps ONE scalar instead of re-deriving it (with its null-pointer select) at every DMA
+            L.ringAddr = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(d0 + o));
         }
     }
     for (;;) {
