@@ -340,7 +340,13 @@ struct WLds {
     // big-factor build: a ring of RING_BYTES in LDS that LDS-DMA loads stream columns into (see "column streams" below)
     const double *ring;
     unsigned ringAddr;  // its LDS byte address (the M0 base of the DMA destination)
+    // big-factor build: the table of forward-substituted BOUND columns (see "bound-column table" below)
+    double *yt;         // global scratch: YT_SLOTS columns of YT_ROWS doubles
+    int16_t *yslot;     // LDS: variable -> its column's slot in yt (valid for the bound variables while the table is live)
+    double *ylnew;      // LDS: the row the last append added to the factor, by column (YT_ROWS doubles)
 };
+[[maybe_unused]] constexpr int YT_SLOTS = 128;
+constexpr int YT_ROWS = 256;
 
 // ------------------------------------------------------------------ column streams through an LDS ring (big-factor build)
 // With one wavefront per SIMD nobody hides a wavefront's memory latency for it, and with 200+ free variables a pass
@@ -552,9 +558,11 @@ __device__ __forceinline__ void fwd_sweep_ring(const WLds &L, int Kin, double (&
     }
 }
 
+// ycol (big-factor build, bound-column table live): L^-1 V[F, j] is already there -- no gather, no sweep.
 template <int SL>
 __device__ __forceinline__ double append_row(const WLds &L, Rows &R, int K, int j, const double *__restrict__ V, int N,
-                                             double (&lnew)[NSL], double (&vraw)[NSL], double (&ysub)[NSL]) {
+                                             double (&lnew)[NSL], double (&vraw)[NSL], double (&ysub)[NSL],
+                                             const double *__restrict__ ycol) {
     const Fac &F = L.F;
     const int lane = lane_id();
     const double *__restrict__ col = V + (size_t)j * N;
@@ -562,6 +570,16 @@ __device__ __forceinline__ double append_row(const WLds &L, Rows &R, int K, int 
     double y[NSL];
 #pragma unroll
     for (int t = 0; t < NSL; ++t) y[t] = 0.0;
+    if (NSL > 2 && ycol != nullptr) {  // uniform
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + KSLOT * t;
+            const double v = ycol[r < K ? r : 0];
+            y[t] = (r < K) ? v : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < NSL; ++t) vraw[t] = 0.0;
+    } else {
 #pragma unroll
     for (int t = 0; t < SL; ++t) {
         const int r = lane + KSLOT * t;
@@ -592,6 +610,7 @@ __device__ __forceinline__ double append_row(const WLds &L, Rows &R, int K, int 
                 for (int t = 0; t < SL; ++t) lc[u][t] = ln[u][t];
         }
     }
+    }
 #pragma unroll
     for (int t = 0; t < NSL; ++t) ysub[t] = y[t];
     double part = 0.0;
@@ -603,6 +622,7 @@ __device__ __forceinline__ double append_row(const WLds &L, Rows &R, int K, int 
         const double tr = (r < K) ? y[t] * R.rd[t] : 0.0;
         part = fma(y[t], tr, part);
         lnew[t] = tr;
+        if (NSL > 2 && ycol != nullptr && r < K) L.ylnew[r] = tr;  // (the table's columns still owe this row their entries)
         if (K < 64) {
             if (t == 0 && r < K) F.L0[cofs64(r) - r + K] = tr;
         } else if (SL >= 2) {
@@ -1101,6 +1121,7 @@ struct WCtx {
     ssqp_trace *trace;
     int ntrace;
     double *lamOut, *gamOut;  // this QP's multiplier outputs (null: not requested)
+    int ytabOn;               // the bound-column table may be used (big-factor build, option)
     int RC;
     long long iter, ret;
     int det;
@@ -1178,7 +1199,7 @@ __device__ __forceinline__ void recompute_H_all(const WLds &L, const Rows &R, in
 //   y_c += dz * y,   H[w][c] += dz * sum_r Y[w]_r lnew_r  (the same sums the new border row needs).
 template <int SL>
 __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int &K, int j, const double2 (&hq)[NCH],
-                                           const double *zg, double dz, double &gz) {
+                                           const double *zg, double dz, double &gz, const double *ycol = nullptr) {
     const int lane = lane_id();
     const int N = C.N, MJ = C.MJ;
     // everything the new row needs from memory is requested before the factor sweep: one round trip, hidden
@@ -1186,7 +1207,7 @@ __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int 
     const double uj = C.uhi[j], dj = C.dlo[j];
     const double zj = __hip_atomic_load(zg + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (written by this wavefront earlier)
     double lnew[NSL], vraw[NSL], ysub[NSL];
-    const double dnew = append_row<SL>(L, R, K, j, C.V, N, lnew, vraw, ysub);
+    const double dnew = append_row<SL>(L, R, K, j, C.V, N, lnew, vraw, ysub, ycol);
     if (!(dnew > 0.0)) return false;
     if (dz != 0.0) {  // uniform
 #pragma unroll
@@ -1249,7 +1270,9 @@ __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int 
     gg_rank1(L, 1.0);
     wave_sync();
     C.sRead += 64ll * K + 64ll * MJ + 16;
-    if (NSL > 2 && SL >= 2 && K > 64) C.sRead += 8ll * ((long long)(K - 64) * 64 + (long long)(K - 64) * (K - 65) / 2);
+    if (NSL > 2 && SL >= 2 && K > 64 && ycol == nullptr)
+        C.sRead += 8ll * ((long long)(K - 64) * 64 + (long long)(K - 64) * (K - 65) / 2);
+    if (ycol != nullptr) C.sRead += 8ll * K;
     K += 1;
     return true;
 }
@@ -1465,6 +1488,10 @@ struct WState {
     unsigned certMask;              // active-row set the full-rank certificate currently holds for (0: none); cleared
                                     // by a deletion from F, kept by appends, valid for every subset of its rows
     bool appAll;                    // append every variable with status IN that has no row (start, after freeK!)
+    // bound-column table (big-factor build)
+    bool ymode;                     // the table is live: yt holds L^-1 V[F, b] for every bound variable b
+    bool ypend;                     // ... up to the row the last append added, whose entries are still owed
+    int yclean;                     // passes since the factor last lost a row
 };
 
 // gamma += sum over the K free columns of V (weights alpha) and the W kept rows of [A;G] (weights alphaL), the columns
@@ -1510,6 +1537,12 @@ __device__ __forceinline__ void gamma_stream(const WCtx &C, const WLds &L, const
 #pragma unroll
         for (int m = 0; m < NI; ++m) vc[m] = vn[m];
     }
+}
+
+// entry e (uniform, e < 128) of a list held two entries per lane (lane l: entries l and 64 + l): no LDS round trip
+__device__ __forceinline__ int list_get(const int (&v)[2], int e) {
+    const int a = __builtin_amdgcn_readlane(v[0], e & 63), b = __builtin_amdgcn_readlane(v[1], e & 63);
+    return e < 64 ? a : b;
 }
 
 // The same gamma when the free variables outnumber the bound ones (K > N - K): V is symmetric, so V[b, F] alpha is the
@@ -1559,9 +1592,14 @@ __device__ __forceinline__ void gamma_dot_stream(const WCtx &C, const WLds &L, c
     if (nb == 0) return;
     // ---- the bound columns, four per round
     const int ngrp = (nb + 3) >> 2;
+    int bv[2];  // (the list in registers, two entries per lane: no LDS round trip per column address)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int e = lane + 64 * h;
+        bv[h] = blist[e < nb ? e : nb - 1];
+    }
     auto colof = [&](int e) -> const double * {  // (entries beyond the list repeat the last column; their sums are dropped)
-        const int b = blist[e < nb ? e : nb - 1];
-        return C.V + (size_t)uni(b) * N;
+        return C.V + (size_t)list_get(bv, e < nb ? e : nb - 1) * N;
     };
     for (int g = 0; g < DB && g < ngrp; ++g)
 #pragma unroll
@@ -1592,7 +1630,7 @@ __device__ __forceinline__ void gamma_dot_stream(const WCtx &C, const WLds &L, c
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (4 * g + u < nb) {  // uniform
-                const int b = uni((int)blist[4 * g + u]);
+                const int b = list_get(bv, 4 * g + u);
                 const int k = dk_of(b);
                 const bool me = lane == dl_of(b);
 #pragma unroll
@@ -1603,6 +1641,258 @@ __device__ __forceinline__ void gamma_dot_stream(const WCtx &C, const WLds &L, c
             }
         }
     }
+}
+
+// ------------------------------------------------------------------ bound-column table (big-factor build)
+// Workloads that end with most variables free (BASELINE config 3: N = 256, K -> 229) spend their passes appending: a full
+// step, the release of one bound variable, the next pass.  Every append needs y = L^-1 V[F, j] (a forward sweep over the
+// whole factor) and every multiplier check needs V[b, F] alpha for the bound b -- although
+//     V[b, F] alpha = -(L^-1 V[F, b])' D^-1 (Y_A alphaL + y_c),
+// the same vector the back substitution starts from.  So once the bound variables are the minority (2K > N) the kernel
+// keeps  yt[b] = L^-1 V[F, b]  for every BOUND b (at most 128 columns of up to 256 rows, in the wavefront's global
+// scratch): an append then READS its column (no sweep), the table's other columns get their entry for the new row --
+// e_b = V[j, b] - l_new . yt[b], the forward substitution's own recurrence -- in the same streaming pass that forms their
+// multipliers, gamma_b = hq_b - yt[b] . v + ([A;G]' alphaL)_b: one pass over R columns of K rows replaces a forward
+// sweep over the factor AND a pass over min(K, R) columns of V.  A pass that takes a row out of the factor (a blocked
+// step) drops the table; it is rebuilt (R forward substitutions, four right-hand sides per sweep of the factor) when the
+// next release comes after a few clean passes.
+template <int SL, int NI, int NRH>
+__device__ __forceinline__ void fwd_sweep_ring_multi(const WLds &L, int Kin, double (&y)[NRH][NSL]) {
+    constexpr int D = RING_BYTES / (1024 * NI);
+    static_assert(D >= 8 && D % 4 == 0, "two groups of four columns in the ring");
+    const int K = uni(Kin);
+    const int ng = (K + 3) >> 2;
+    for (int c = 0; c < D && c < 4 * ng; ++c) ring_issue_faccol<NI>(L, c, c, K);
+    double lc[4][NSL], ln[4][NSL];
+    wait_all_landed();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ring_read_faccol<SL, NI>(L, K, u, lc[u]);
+    for (int g = 0; g < ng; ++g) {
+        const int c0 = 4 * g;
+        const bool more = c0 + D < 4 * ng;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ring_issue_faccol<NI>(L, (c0 + u) % D, c0 + D + u, K);
+        }
+        if (g + 1 < ng) {
+            if (more) wait_vm<NI * (D - 4)>();
+            else wait_vm<0>();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ring_read_faccol<SL, NI>(L, K, c0 + 4 + u, ln[u]);
+        }
+        {
+            const int tb = c0 >> 6, l0 = c0 & 63;
+            sfor<0, SL>(SFOR_BODY(tq) {
+                SFOR_IDX(tq);
+                if (tb == tq) {  // uniform
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (c0 + u < K) {  // uniform
+#pragma unroll
+                            for (int q = 0; q < NRH; ++q) {
+                                const double yc = readlane_f64(y[q][tq], l0 + u);
+#pragma unroll
+                                for (int t = tq; t < SL; ++t) y[q][t] = fma(-lc[u][t], yc, y[q][t]);
+                            }
+                        }
+                    }
+                }
+            });
+        }
+        wait_lds();
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < NSL; ++t) lc[u][t] = ln[u][t];
+    }
+}
+
+// the bound variables (status != IN) listed in `blist` (int16, LDS); returns their number (uniform).  N <= 256.
+__device__ __forceinline__ int list_bound(unsigned Sp, int N, int16_t *blist) {
+    const int lane = lane_id();
+    int nb = 0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int i0 = 2 * lane + 128 * m;
+        const bool bx = i0 < N && st_of(Sp, 2 * m) != SSQP_IN, by = i0 + 1 < N && st_of(Sp, 2 * m + 1) != SSQP_IN;
+        const unsigned long long mx = __ballot(bx), my = __ballot(by);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const int pos = nb + __popcll(mx & lt) + __popcll(my & lt);
+        if (bx) blist[pos] = (int16_t)i0;
+        if (by) blist[pos + (bx ? 1 : 0)] = (int16_t)(i0 + 1);
+        nb += __popcll(mx) + __popcll(my);
+    }
+    return uni(nb);
+}
+
+// (re)build the table for the current factor (K rows) and bound set: slot = position in the list
+template <int SL>
+__device__ __forceinline__ void ytab_init(WCtx &C, const WLds &L, const Rows &R, int Kin, unsigned Sp) {
+    const int lane = lane_id();
+    const int N = uni(C.N), K = uni(Kin);
+    int16_t *blist = reinterpret_cast<int16_t *>(L.tr);
+    wave_sync();
+    const int nb = list_bound(Sp, N, blist);
+    wave_sync();
+    for (int e = lane; e < nb; e += 64) L.yslot[blist[e]] = (int16_t)e;
+    wave_sync();
+    for (int g = 0; g < nb; g += 4) {
+        double y[4][NSL];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = uni((int)blist[g + u < nb ? g + u : nb - 1]);
+            const double *__restrict__ col = C.V + (size_t)b * N;
+#pragma unroll
+            for (int t = 0; t < NSL; ++t) y[u][t] = 0.0;
+#pragma unroll
+            for (int t = 0; t < SL; ++t) {
+                const int r = lane + KSLOT * t;
+                const double v = col[r < K ? R.ord[t] : 0];
+                y[u][t] = (r < K) ? v : 0.0;
+            }
+        }
+        if (K <= 192) fwd_sweep_ring_multi<SL, 1, 4>(L, K, y);
+        else fwd_sweep_ring_multi<SL, 2, 4>(L, K, y);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (g + u < nb) {  // uniform
+                double *__restrict__ dst = L.yt + (size_t)(g + u) * YT_ROWS;
+#pragma unroll
+                for (int t = 0; t < SL; ++t) {
+                    const int r = lane + KSLOT * t;
+                    if (r < K) dst[r] = y[u][t];
+                }
+            }
+        }
+        C.sRead += 4ll * 64 * K;
+        if (K > 64) C.sRead += 8ll * ((long long)(K - 64) * 64 + (long long)(K - 64) * (K - 65) / 2);
+    }
+    wave_sync();
+}
+
+// gamma through the table: gam (= hq on entry) += [A;G][kept,:]' alphaL - yt[b] . v on every bound b; when `pend`, the
+// table's columns first get their entry for the factor's newest row (row K - 1, variable jnew), which the dot product
+// with v then includes.  v = D^-1 (Y_A alphaL + y_c) is formed again from the border rows (the back substitution has
+// overwritten it).
+template <int SL, int NIV>
+__device__ __forceinline__ void gamma_ytab(WCtx &C, const WLds &L, const Rows &R, int Kin, int Win, unsigned kept,
+                                           const double (&alpha)[NSL], double alRow, int raLane, double2 (&gam)[NCH],
+                                           unsigned Sp, bool pend) {
+    constexpr int NI = 2, D = RING_BYTES / (1024 * NI), DB = D / 4;
+    const int lane = lane_id();
+    const int N = uni(C.N), K = uni(Kin);
+    // ---- [A;G][kept,:]' alphaL by the column stream (no free column: K = 0 there)
+    gamma_stream<SL, NIV>(C, L, R, 0, Win, alpha, alRow, raLane, gam);
+    // ---- v, the new row of the factor, row jnew of V
+    double vv[NSL], ln[NSL];
+#pragma unroll
+    for (int t = 0; t < NSL; ++t) vv[t] = ln[t] = 0.0;
+#pragma unroll
+    for (int t = 0; t < SL; ++t) vv[t] = R.Y[CC][t];
+#pragma unroll
+    for (int w = 0; w < MJX; ++w) {
+        if ((kept >> w) & 1u) {  // uniform
+            const double al = readlane_f64(alRow, w);
+#pragma unroll
+            for (int t = 0; t < SL; ++t) vv[t] = fma(R.Y[w][t], al, vv[t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int r = lane + KSLOT * t;
+        vv[t] = (r < K) ? vv[t] * R.rd[t] : 0.0;
+    }
+    const int nrow = pend ? K - 1 : K;  // rows the table's columns hold
+    double vK = 0.0;
+    double2 vj[2];
+    vj[0] = vj[1] = make_double2(0.0, 0.0);
+    if (pend) {  // uniform
+        vK = rbcast<SL>(vv, K - 1);
+        const int jnew = rbcast_i<SL>(R.ord, K - 1);
+        const double *__restrict__ colj = C.V + (size_t)jnew * N;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int i0 = 2 * lane + 128 * m;
+            vj[m] = *reinterpret_cast<const double2 *>(colj + (i0 < N ? i0 : 0));
+        }
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+            const int r = lane + KSLOT * t;
+            ln[t] = (r < K - 1) ? L.ylnew[r] : 0.0;
+        }
+    }
+    // ---- the bound variables and their columns, four per round
+    int16_t *blist = reinterpret_cast<int16_t *>(L.tr);
+    wave_sync();
+    const int nb = list_bound(Sp, N, blist);
+    wave_sync();
+    if (nb == 0) return;
+    // (the list and the columns' slots go to registers, two entries per lane: a column's address then costs two
+    //  v_readlane instead of two dependent LDS round trips)
+    int bv[2], bs[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int e = lane + 64 * h;
+        bv[h] = blist[e < nb ? e : nb - 1];
+        bs[h] = L.yslot[bv[h]];
+    }
+    const int ngrp = (nb + 3) >> 2;
+    const int nld = (nrow + 1) & ~1;  // doubles requested per column (even; the row behind the last is inside the slot)
+    auto colof = [&](int e) -> const double * { return L.yt + (size_t)list_get(bs, e < nb ? e : nb - 1) * YT_ROWS; };
+    for (int g = 0; g < DB && g < ngrp; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ring_issue_dense<NI>(L, (4 * g + u) % D, colof(4 * g + u), nld);
+    wait_all_landed();
+    for (int g = 0; g < ngrp; ++g) {
+        if (g + DB <= ngrp) wait_vm<NI * (D - 4)>();
+        else wait_vm<0>();
+        double prod[8], sums[8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double *__restrict__ slot = L.ring + (size_t)((4 * g + u) % D) * (128 * NI);
+            double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+            for (int t = 0; t < SL; ++t) {
+                const int r = lane + KSLOT * t;
+                const double y = slot[r];
+                const bool in = r < nrow;
+                d1 = in ? fma(ln[t], y, d1) : d1;
+                d2 = in ? fma(vv[t], y, d2) : d2;
+            }
+            prod[u] = d1;
+            prod[4 + u] = d2;
+        }
+        wait_lds();
+        if (g + DB < ngrp) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ring_issue_dense<NI>(L, (4 * g + u) % D, colof(4 * (g + DB) + u), nld);
+        }
+        wave_sum_multi<8>(prod, sums);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (4 * g + u < nb) {  // uniform
+                const int b = list_get(bv, 4 * g + u);
+                const int k = dk_of(b), l = dl_of(b);
+                double tot = sums[4 + u];
+                if (pend) {  // uniform
+                    const double v0 = readlane_f64(vj[0].x, l), v1 = readlane_f64(vj[0].y, l);
+                    const double v2 = readlane_f64(vj[1].x, l), v3 = readlane_f64(vj[1].y, l);
+                    const double vjb = (k == 0) ? v0 : ((k == 1) ? v1 : ((k == 2) ? v2 : v3));
+                    const double eb = vjb - sums[u];
+                    tot = fma(vK, eb, tot);
+                    if (lane == 0) L.yt[(size_t)list_get(bs, 4 * g + u) * YT_ROWS + (K - 1)] = eb;
+                }
+                const bool me = lane == l;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    gam[m].x -= (me && k == 2 * m) ? tot : 0.0;
+                    gam[m].y -= (me && k == 2 * m + 1) ? tot : 0.0;
+                }
+            }
+        }
+    }
+    wave_sync();  // (the new entries are in memory before the next pass streams the columns again)
+    C.sRead += 8ll * nrow * nb + 8ll * N * Win + (pend ? 8ll * N : 0ll);
 }
 
 // One pass for K > 0 with the kept factor in sync.  SSQP.jl:287-375.
@@ -1854,7 +2144,11 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
     double2 gam[NCH];
 #pragma unroll
     for (int m = 0; m < NCH; ++m) gam[m] = S.hq[m];
-    if (NSL > 2) {  // (big-factor build: the list below streamed through the LDS ring)
+    if (NSL > 2 && SL == NSL && S.ymode) {  // (big-factor build: through the bound-column table)
+        if (N <= 128) gamma_ytab<SL, 1>(C, L, R, K, W, kept, alpha, alRow, raLane, gam, S.Sp, S.ypend);
+        else gamma_ytab<SL, 2>(C, L, R, K, W, kept, alpha, alRow, raLane, gam, S.Sp, S.ypend);
+        S.ypend = false;
+    } else if (NSL > 2) {  // (big-factor build: the list below streamed through the LDS ring)
         if (SL >= 2 && N <= 256 && 2 * K > N) {  // fewer bound than free variables: by the bound columns (V is symmetric)
             if (N <= 128) gamma_dot_stream<SL, 1>(C, L, R, K, W, alpha, alRow, raLane, gam, S.Sp);
             else gamma_dot_stream<SL, 2>(C, L, R, K, W, alpha, alRow, raLane, gam, S.Sp);
@@ -2016,6 +2310,12 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
     if (ev.v < INF) {  // release the single tightest one (:175-184)
         if (ev.ord < N) {
             const int jv = ev.ord;
+            if (NSL > 2 && SL == NSL && C.ytabOn && !S.ymode && N <= 256 && 2 * K > N && S.yclean >= 3) {
+                // appends ahead and the bound variables in the minority: from here on they come out of the table
+                ytab_init<SL>(C, L, R, K, S.Sp);  // (jv is still bound: its column is the next append)
+                S.ymode = true;
+                S.ypend = false;
+            }
             st_set(S.Sp, jv, SSQP_IN);
             const double zr = __hip_atomic_load(S.zg + jv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             S.relDz = 0.0;
@@ -2116,6 +2416,9 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
     for (int t = 0; t < NSL; ++t) ndel += __popcll(S.del[t]);
     if (ndel > 0) {
         S.certMask = 0u;  // (a column of AE goes: the Gram pivots may shrink)
+        S.ymode = false;  // (the factor loses a row: the bound-column table is dropped)
+        S.ypend = false;
+        S.yclean = 0;
         const bool single = (ndel == 1);
         // A single deletion with one register slot: the border rows follow by a scan and H by the downdate, and when
         // the variable went to a nonzero bound the change of c is folded in beforehand -- no re-gather, no re-sweep.
@@ -2183,7 +2486,17 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
         S.relDz = 0.0;
         if (S.appJ >= 0) {
             if (S.K + 1 > C.RC) return W_HANDOVER;
-            if (!append_var<SL>(C, L, R, S.K, S.appJ, S.hq, S.zg, dzFold, S.gz)) {
+            const double *ycol = nullptr;
+            if (NSL > 2 && S.ymode) {
+                if (SL == NSL && !S.ypend) {
+                    ycol = L.yt + (size_t)uni((int)L.yslot[S.appJ]) * YT_ROWS;
+                    S.ypend = true;
+                } else {
+                    S.ymode = false;  // (cannot happen: a release implies the table was brought up to date; be safe)
+                    S.ypend = false;
+                }
+            }
+            if (!append_var<SL>(C, L, R, S.K, S.appJ, S.hq, S.zg, dzFold, S.gz, ycol)) {
                 C.ret = -1;
                 C.det = SSQP_DETAIL_POSDEF_V;
                 return W_BREAK;
@@ -2277,6 +2590,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     C.lamOut = P.lamOut ? P.lamOut + (size_t)prob * MJ : nullptr;
     C.gamOut = P.gamOut ? P.gamOut + (size_t)prob * N : nullptr;
     C.RC = P.waveRC;
+    C.ytabOn = (NSL > 2) ? P.waveYtab : 0;
     // hand-over from a build with a smaller factor (P.resume): continue from its (z, S) at its pass count
     C.iter = (CAN_RESUME && P.resume) ? P.fbIter[prob] : 0;
     C.ret = 0; C.det = SSQP_DETAIL_NONE;
@@ -2330,6 +2644,9 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     S.blkDz = 0.0;
     S.certMask = 0u;
     S.appAll = true;
+    S.ymode = false;
+    S.ypend = false;
+    S.yclean = 0;
     if (PARK) slot1_store(S.R, park);
     for (int e = lane; e < NR * NR; e += 64) L.H[e] = 0.0;
     for (int e = lane; e < MJX * MJX; e += 64) L.GG[e] = 0.0;
@@ -2359,7 +2676,10 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
         int Knew = S.K + (S.appJ >= 0 ? 1 : 0);
 #pragma unroll
         for (int t = 0; t < NSL; ++t) Knew -= __popcll(S.del[t]);
+        S.yclean += 1;
         if (S.appAll) {
+            S.ymode = false;
+            S.ypend = false;
             int nin = 0;
 #pragma unroll
             for (int k = 0; k < 8; ++k)
@@ -2575,7 +2895,15 @@ __global__ __launch_bounds__(64, WPS) void ssqp_wave_kernel(SolveParams P) {
         o += 8;
         L.ring = nullptr;
         L.ringAddr = 0u;
+        L.yt = nullptr;
+        L.yslot = nullptr;
+        L.ylnew = nullptr;
         if (NSL > 2) {
+            L.yslot = reinterpret_cast<int16_t *>(d0 + o);
+            o += YT_ROWS / 4;           // (one int16 per variable, N <= 256 while the table is in use)
+            L.ylnew = d0 + o;
+            o += YT_ROWS;
+            L.yt = gscr + WAVE_LS_DOUBLES_BIG + 256 * 192 + 64;
             o = (o + 127) / 128 * 128;  // (1 KiB alignment of the DMA pieces)
             L.ring = d0 + o;
             // low half of the flat address of an LDS location = its LDS byte address; read through v_readfirstlane so that
@@ -2647,13 +2975,14 @@ int wave_lds_bytes(int rc) {  // rc <= 0: the builds that keep rows >= 64 in glo
     const int dbl = 2080 + l1 + NR * NR + 2 * (MJX * MJX + 1) + 16 * 3 + 8;
     return dbl * 8;
 }
-int wave_lds_bytes_big() {  // big-factor build: the same without LDS rows >= 64, plus the column ring (1 KiB aligned)
-    return (wave_lds_bytes(0) + 1023) / 1024 * 1024 + RING_BYTES;
+int wave_lds_bytes_big() {  // big-factor build: the same without LDS rows >= 64, the bound-column table's slot map and
+                            // new-row vector, plus the column ring (1 KiB aligned)
+    return (wave_lds_bytes(0) + (YT_ROWS / 4 + YT_ROWS) * 8 + 1023) / 1024 * 1024 + RING_BYTES;
 }
 size_t wave_scratch_doubles(int variant) {
     // least-squares scratch, then (eight-per-CU build) rows 64..127 of up to 128 columns of the factor and the parked
     // second row slot; (big-factor build) rows 64..255 of up to 256 columns
-    if (variant == 2) return (size_t)WAVE_LS_DOUBLES_BIG + 256 * 192 + 64;
+    if (variant == 2) return (size_t)WAVE_LS_DOUBLES_BIG + 256 * 192 + 64 + (size_t)YT_SLOTS * YT_ROWS + 64;
     return (size_t)WAVE_LS_DOUBLES + 128 * 64 + PARK_FIELDS * 64 + 64;
 }
 hipError_t launch_solve_wave(const SolveParams &P, int grid, int variant, hipStream_t stream) {
