@@ -119,11 +119,6 @@ const char *ssqp_last_error(const ssqp_ctx *ctx);
  *   "dense_gamma"     1: the reference's dense formulation (from-scratch factor, gamma pass over all N columns,
  *                     SSQP.jl:322,352) -- the HBM roofline measurement; default 0
  *   "wg_per_cu"       workgroups per CU of the workgroup kernel: 0 = automatic (default), 1, 2
- *   "wave_ytab"       1: the big-factor build keeps L^-1 V[F, b] for every bound variable b once the bound variables are
- *                     the minority, so that an append reads its column instead of sweeping the factor and the multiplier
- *                     pass streams that table instead of columns of V.  Same results; experimental and off by default (0):
- *                     the table is rebuilt after every pass that takes a row out of the factor, which on BASELINE config 3
- *                     costs more than the table saves (34.5 against 27.1 ms per batch)
  *   "lazy_handover"   1: the launch of the workgroup kernel on the wavefront kernel's hand-over list is not queued
  *                     behind it but issued by ssqp_sync (or the next call on the context) and only when the list is
  *                     not empty -- for hosts that keep several contexts busy on different streams (the queued launch

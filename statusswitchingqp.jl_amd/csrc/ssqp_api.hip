@@ -36,8 +36,6 @@ struct ssqp_ctx {
     int optWaveKernel = 1;   // 0: never use the wavefront-per-QP kernel; 2: start in its big-factor build
     int optWaveQPC = 0;      // QPs (wavefronts) per CU of the wavefront kernel: 0 = by batch size, 1..4, 8
     int optLazyHandover = 0; // 1: the hand-over launch is deferred to ssqp_sync / the next call and skipped when empty
-    int optWaveYtab = 0;     // big-factor build: 1 = keep the bound-column table (experimental: correct, but rebuilding it
-                             // after every pass that takes a row out of the factor costs more than it saves on cfg3)
     int optPinHost = 0;      // 1: page-lock the caller's V array (kept registered until another array comes)
     const void *pinnedPtr = nullptr;
     size_t pinnedBytes = 0;
@@ -179,7 +177,6 @@ static int *option_slot(ssqp_ctx *c, const char *name) {
     if (!std::strcmp(name, "wave_qp_per_cu")) return &c->optWaveQPC;
     if (!std::strcmp(name, "pin_host_buffers")) return &c->optPinHost;
     if (!std::strcmp(name, "lazy_handover")) return &c->optLazyHandover;
-    if (!std::strcmp(name, "wave_ytab")) return &c->optWaveYtab;
     return nullptr;
 }
 int ssqp_ctx_set_option(ssqp_ctx *c, const char *name, int value) {
@@ -191,8 +188,7 @@ int ssqp_ctx_set_option(ssqp_ctx *c, const char *name, int value) {
     if ((slot == &c->optWgPerCU && (value < 0 || value > ssqp::MAX_WG_PER_CU)) ||
         (slot == &c->optWaveQPC && (value < 0 || value > 8)) ||
         (slot == &c->optWaveKernel && (value < 0 || value > 2)) ||
-        ((slot == &c->optDenseGamma || slot == &c->optIncremental || slot == &c->optPinHost || slot == &c->optLazyHandover ||
-          slot == &c->optWaveYtab) &&
+        ((slot == &c->optDenseGamma || slot == &c->optIncremental || slot == &c->optPinHost || slot == &c->optLazyHandover) &&
          (value != 0 && value != 1))) {
         c->err = std::string("option value out of range: ") + name;
         return SSQP_ERR_ARG;
@@ -403,7 +399,6 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
     P.wscratchStride = wstride;
     P.waveLdsBytes = waveLds;
     P.waveRC = waveRC;
-    P.waveYtab = c->optWaveYtab;
     P.arenaCap = ((ldsPerWG - fixed - 64) / 16) * 2;
     if (P.arenaCap < 0) P.arenaCap = 0;
     const ssqp::LdsLayout lay = ssqp::lds_layout(N, M, J, P.arenaCap);
@@ -509,7 +504,6 @@ static ssqp_ctx *lane_of(ssqp_ctx *c, int i) {
     l->optIncremental = c->optIncremental;
     l->optWaveKernel = c->optWaveKernel;
     l->optWaveQPC = c->optWaveQPC;
-    l->optWaveYtab = c->optWaveYtab;
     l->optLazyHandover = 1;  // (the batch entry finishes every lane before it copies the results back)
     return l;
 }

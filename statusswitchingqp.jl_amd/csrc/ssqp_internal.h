@@ -62,7 +62,6 @@ struct SolveParams {
     size_t wscratchStride;   // doubles per wavefront
     int waveLdsBytes;        // wavefront kernel: dynamic LDS per wavefront
     int waveRC;              // wavefront kernel: row capacity of the kept factor
-    int waveYtab;            // big-factor build: keep the table of forward-substituted bound columns (option "wave_ytab")
 };
 
 // Offsets of the LDS carve-up.  Double-typed regions first (offsets in

@@ -208,8 +208,7 @@ def test_big_factor_build_families(pkg, orc, family):
     assert (sto > 0).all()
     ctx = pkg.default_context()
     seen_big = False
-    # (wave_ytab = 1: the experimental bound-column table of the big-factor build -- appends read their column from it)
-    for opts in (dict(), dict(wave_qp_per_cu=8), dict(wave_kernel=2), dict(wave_ytab=1)):
+    for opts in (dict(), dict(wave_qp_per_cu=8), dict(wave_kernel=2)):
         with ctx.options(**opts):
             z, S, status, detail, stats = pkg.solveQP_batch(sub, S0[ok], x0[ok], want_stats=True)
         assert_parity(z, S, status, zo, So, sto)
