@@ -314,6 +314,8 @@ struct Fac {
     double *L0;  // rows and columns < 64: packed columns, column c holds rows c..63 at cofs64(c) (slot c unused)
     double *L1;  // rows >= 64: element (r, c) at c * R1 + (r - 64)
     int R1;
+    double *LR;  // big-factor build: the same rows once more BY ROWS, element (r, c) at (r - 64) * LR_STRIDE + c, zero for
+                 // c >= r and in the rows >= K (what the back substitution streams)
 };
 __device__ __forceinline__ int cofs64(int c) { return c * 64 - ((c * (c - 1)) >> 1); }
 
@@ -410,6 +412,8 @@ __device__ __forceinline__ void ring_issue_dense(const WLds &L, int slot, const 
 // is pointed at rows 254, 255 of the same column (K <= 252: zero for ever), the slot holds zeros wherever the column
 // has no entry and the reader needs no mask.  TRI = false: the caller knows c < 64 (every row >= 64 lies below).
 constexpr unsigned FAC_ZERO_OFF = 190u * 8u;
+constexpr int LR_STRIDE = 256;
+constexpr unsigned ROW_ZERO_OFF = 254u * 8u;  // (row r holds zeros from column r on; r <= 251)
 template <int NI>
 __device__ __forceinline__ void faccol_offsets(int K, unsigned (&vo)[NI]) {
     const int lane = lane_id();
@@ -504,14 +508,15 @@ __device__ __forceinline__ void fac_put(const Fac &F, int r, int c, double v, bo
 // where lane <= c -- no select on the DATA, so the reads of a group of columns go out back to back, straight into the
 // registers that keep them, and are waited for once.
 template <int SL, int NI, int TB>
-__device__ __forceinline__ void ring_read_faccol(const WLds &L, int K, int c, double (&l)[NSL]) {
+__device__ __forceinline__ void ring_read_faccol(const WLds &L, int K, int c, double (&l)[NSL], int slotIdx = -1) {
     constexpr int D = RING_BYTES / (1024 * NI);
     const int lane = lane_id();
+    if (slotIdx < 0) slotIdx = c % D;
     if (TB == 0) {
         const int c0 = c < 63 ? c : 63;
         l[0] = L.F.L0[(lane > c && lane < K) ? cofs64(c0) - c0 + lane : L.zidx];  // (rows >= K of L0 are stale)
     }
-    const double *__restrict__ slot = L.ring + (size_t)(c % D) * (128 * NI);
+    const double *__restrict__ slot = L.ring + (size_t)slotIdx * (128 * NI);
 #pragma unroll
     for (int t = (TB > 1 ? TB : 1); t < SL; ++t)
         if (KSLOT * (t - 1) < 128 * NI) l[t] = slot[KSLOT * (t - 1) + lane];  // (compile-time: the slot holds rows 64 .. 64 + 128 NI - 1)
@@ -522,8 +527,10 @@ __device__ __forceinline__ void ring_read_faccol(const WLds &L, int K, int c, do
 // round's entries come out of LDS together (one wait) while this round's are applied.  The loop is written out once per
 // register slot the columns lie in (64 is a multiple of 4: a group's rows sit in ONE slot), so that which slots a group
 // reads and updates is known at compile time.  Columns K .. 4 ng - 1 are all zero: applied like the others.
-template <int SL, int NI>
-__device__ __forceinline__ void fwd_sweep_ring(const WLds &L, int Kin, double (&y)[NSL]) {
+// ap(IC<tb>, l, lc): apply column (64 tb + l) of the factor, whose entries for this lane's rows are lc, to the right-hand
+// side(s) -- y_c is final when its column comes up.
+template <int SL, int NI, class AP>
+__device__ __forceinline__ void fwd_sweep_ring(const WLds &L, int Kin, AP &&ap) {
     constexpr int D = RING_BYTES / (1024 * NI);
     static_assert(D >= 8 && D % 4 == 0 && D <= 64, "two groups of four columns in the ring; the prologue stays below column 64");
     const int K = uni(Kin);
@@ -558,11 +565,7 @@ __device__ __forceinline__ void fwd_sweep_ring(const WLds &L, int Kin, double (&
             }
             const int l0 = c0 & 63;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double yc = readlane_f64(y[tb], l0 + u);
-#pragma unroll
-                for (int t = tb; t < SL; ++t) y[t] = fma(-lc[u][t], yc, y[t]);  // (slots above hold rows <= c: no entry)
-            }
+            for (int u = 0; u < 4; ++u) ap(IC<tb>{}, l0 + u, lc[u]);
             wait_lds();  // (ln has arrived: the slots of group g + 1 are free for the next round's request)
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -593,8 +596,14 @@ __device__ __forceinline__ double append_row(const WLds &L, Rows &R, int K, int 
 #pragma unroll
     for (int t = 0; t < NSL; ++t) vraw[t] = y[t];
     if (NSL > 2 && SL >= 2) {
-        if (K <= 192) fwd_sweep_ring<SL, 1>(L, K, y);
-        else fwd_sweep_ring<SL, 2>(L, K, y);
+        auto ap = [&](auto tbc, int l, const double (&lc)[NSL]) __attribute__((always_inline)) {
+            constexpr int tb = decltype(tbc)::value;
+            const double yc = readlane_f64(y[tb], l);
+#pragma unroll
+            for (int t = tb; t < SL; ++t) y[t] = fma(-lc[t], yc, y[t]);  // (slots above hold rows <= c: no entry)
+        };
+        if (K <= 192) fwd_sweep_ring<SL, 1>(L, K, ap);
+        else fwd_sweep_ring<SL, 2>(L, K, ap);
     } else {
         double lc[4][NSL], ln[4][NSL];
         load_cols4<SL>(F, K, 0, lc);
@@ -630,6 +639,10 @@ __device__ __forceinline__ double append_row(const WLds &L, Rows &R, int K, int 
         } else if (SL >= 2) {
             if (r < K) F.L1[r * F.R1 + (K - 64)] = tr;
         }
+    }
+    if (NSL > 2 && SL >= 2 && K >= 64) {  // the same row in the by-rows copy, zeros from column K on
+#pragma unroll
+        for (int t = 0; t < NSL; ++t) F.LR[(size_t)(K - 64) * LR_STRIDE + lane + KSLOT * t] = lnew[t];
     }
     const double dnew = vjj - wave_sum(part);
     wave_sync();
@@ -728,12 +741,122 @@ __device__ __forceinline__ void delete_compact(const Fac &F, int K, int p) {
         }
         wave_sync();
     }
-    if (NSL > 2 && SL >= 2 && K - 1 >= 64) {  // the row this frees goes back to zero (ring_issue_faccol relies on it)
+    wave_sync();
+}
+
+// The big-factor build's delete: delete_update and delete_compact in ONE pass over the factor, the global part of every
+// column streamed through the ring.  Columns k > p are updated (the rank-1 recurrence above) and written straight to
+// where the compaction would move them -- column k - 1, rows r - 1 (that storage has been consumed: the stream runs
+// ahead of the writes); columns c < p only lose row p (their rows > p move up by one).  Both copies of the rows >= 64 are
+// maintained (by columns: coalesced; by rows: one scattered store per slot and column), and the row the factor loses is
+// zeroed in both (ring_issue_faccol / ring_issue_facrow rely on zeros outside the factor).
+// Stores and DMA loads share the vmcnt counter and complete out of order with respect to each other, so a counted wait
+// cannot tell "the oldest column has landed" here: the ring is used as two halves of four columns -- the next group is
+// requested, this group is processed (with its stores), then vmcnt(0).
+template <int SL, int NI>
+__device__ __forceinline__ void delete_stream(const WLds &L, Rows &R, int Kin, int pin, double (&pv)[NSL], double (&bt)[NSL]) {
+    const Fac &F = L.F;
+    const int lane = lane_id();
+    const int K = uni(Kin), p = uni(pin);
+    double w[NSL];
+    load_col<SL>(F, K, p, w);  // column p (rows > p), before its storage is overwritten
+#pragma unroll
+    for (int t = 0; t < NSL; ++t) pv[t] = bt[t] = 0.0;
+    unsigned vo[NI];
+    faccol_offsets<NI>(K, vo);
+    double lc[4][NSL];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < NSL; ++t) lc[u][t] = 0.0;
+    auto put = [&](int rn, int cn, double val, bool on) __attribute__((always_inline)) {  // element (rn, cn) of the new factor
+        if (on && rn >= 64) {
+            F.L1[cn * F.R1 + (rn - 64)] = val;
+            F.LR[(size_t)(rn - 64) * LR_STRIDE + cn] = val;
+        }
+        if (on && rn < 64) F.L0[cofs64(cn) - cn + rn] = val;  // (rn < 64: cn < rn < 64)
+    };
+    wait_all_landed();
+    // ---- columns c < p: rows r > p move up by one
+    if (p > 0 && p < K - 1) {  // uniform
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ring_issue_faccol<NI, true>(L, u, u, vo);
+        wait_vm<0>();
+        for (int j = 0, c0 = 0; c0 < p; ++j, c0 += 4) {
+            const int sb = (j & 1) * 4;
+            if (c0 + 4 < p) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ring_issue_faccol<NI, true>(L, (4 - sb) + u, c0 + 4 + u, vo);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ring_read_faccol<SL, NI, 0>(L, K, c0 + u, lc[u], sb + u);
+            wait_lds();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (c0 + u < p) {  // uniform
+                    shift_up<SL>(lc[u], p);  // lane of row rn >= p now holds the old row rn + 1
+#pragma unroll
+                    for (int t = 0; t < SL; ++t) {
+                        const int rn = lane + KSLOT * t;
+                        put(rn, c0 + u, lc[u][t], rn >= p && rn + 1 < K);
+                    }
+                }
+            }
+            wait_vm<0>();
+        }
+    }
+    // ---- columns k > p: the rank-1 update, written to column k - 1, rows r - 1
+    double alpha = rbcast<SL>(R.dg, p);
+    if (p + 1 < K) {  // uniform
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ring_issue_faccol<NI, true>(L, u, p + 1 + u, vo);
+        wait_vm<0>();
+        for (int j = 0, k0 = p + 1; k0 < K; ++j, k0 += 4) {
+            const int sb = (j & 1) * 4;
+            if (k0 + 4 < K) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ring_issue_faccol<NI, true>(L, (4 - sb) + u, k0 + 4 + u, vo);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ring_read_faccol<SL, NI, 0>(L, K, k0 + u, lc[u], sb + u);
+            wait_lds();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u;
+                if (k < K) {  // uniform
+                    const double pk = rbcast<SL>(w, k);
+                    const double dk = rbcast<SL>(R.dg, k);
+                    const double dn = fma(alpha * pk, pk, dk);
+                    const double rdn = fast_rcp(dn);
+                    const double beta = pk * alpha * rdn;
+                    alpha = alpha * dk * rdn;
+#pragma unroll
+                    for (int t = 0; t < SL; ++t) {
+                        const int r = lane + KSLOT * t;
+                        if (r == k) {
+                            R.dg[t] = dn;
+                            R.rd[t] = rdn;
+                            pv[t] = pk;
+                            bt[t] = beta;
+                        }
+                        const bool below = r > k && r < K;
+                        w[t] = below ? fma(-pk, lc[u][t], w[t]) : w[t];
+                        put(r - 1, k - 1, fma(beta, w[t], lc[u][t]), below);
+                    }
+                }
+            }
+            wait_vm<0>();
+        }
+    }
+    // ---- the row the factor loses: zero in both copies
+    if (K - 1 >= 64) {
 #pragma unroll
         for (int t = 0; t < SL; ++t) {
             const int c = lane + KSLOT * t;
             if (c < K - 1) F.L1[c * F.R1 + (K - 1 - 64)] = 0.0;
         }
+#pragma unroll
+        for (int t = 0; t < NSL; ++t) F.LR[(size_t)(K - 1 - 64) * LR_STRIDE + lane + KSLOT * t] = 0.0;
     }
     wave_sync();
 }
@@ -741,7 +864,7 @@ __device__ __forceinline__ void delete_compact(const Fac &F, int K, int p) {
 // forward substitution L y = b of the border columns selected by `cols` (bit w), from their raw right-hand sides
 template <int SL>
 __device__ __forceinline__ void border_sweep(const Fac &F, Rows &R, int K, unsigned cols, const double *__restrict__ Ct,
-                                             int N, const double2 (&hq)[NCH]) {
+                                             int N, const double2 (&hq)[NCH], const WLds *Lw = nullptr) {
     const int lane = lane_id();
 #pragma unroll
     for (int w = 0; w < NR; ++w) {
@@ -760,6 +883,22 @@ __device__ __forceinline__ void border_sweep(const Fac &F, Rows &R, int K, unsig
                 for (int t = 0; t < SL; ++t) R.Y[w][t] = x[t];
             }
         }
+    }
+    if (NSL > 2 && SL >= 2) {  // (big-factor build: the factor's columns streamed through the ring)
+        auto ap = [&](auto tbc, int l, const double (&lcol)[NSL]) __attribute__((always_inline)) {
+            constexpr int tb = decltype(tbc)::value;
+#pragma unroll
+            for (int w = 0; w < NR; ++w) {
+                if ((cols >> w) & 1u) {  // uniform
+                    const double yc = readlane_f64(R.Y[w][tb], l);
+#pragma unroll
+                    for (int t = tb; t < SL; ++t) R.Y[w][t] = fma(-lcol[t], yc, R.Y[w][t]);
+                }
+            }
+        };
+        if (K <= 192) fwd_sweep_ring<SL, 1>(*Lw, K, ap);
+        else fwd_sweep_ring<SL, 2>(*Lw, K, ap);
+        return;
     }
     double lc[4][NSL], ln[4][NSL];
     load_cols4<SL>(F, K, 0, lc);
@@ -835,83 +974,107 @@ __device__ __forceinline__ void back_sweep(const Fac &F, int K, double (&v)[NSL]
     }
 }
 
-// The same back substitution for factors whose rows >= 64 live in global memory (the big-factor build): reading a ROW of
-// the column-major storage costs one cache line per lane, so the sweep goes by COLUMNS instead -- column c holds
-// L(r, c) for the rows r > c contiguously, x_c = v_c - sum_{r > c} L(r, c) x_r is a sum over lanes.  Four columns per
-// round: their partial sums over the rows above the block come out of one multi-vector butterfly, the 4 x 4 triangle
-// inside the block is resolved with scalar broadcasts; the next round's columns are requested before this round's sums.
+// The back substitution of the big-factor build goes by ROWS: once x_r is final, v_c -= L(r, c) x_r for every c < r is
+// an AXPY with row r of the factor -- no sum over lanes, no triangle to resolve inside a block.  Row r of the
+// column-major storage would cost one cache line per lane, so the build keeps the rows >= 64 a second time by rows
+// (Fac::LR: an append writes its row to both, a delete re-forms the rows it changed) and streams them through the ring
+// from the last row down, four rows per round, the loop written out once per register slot the rows lie in.  Rows < 64
+// come from the packed columns in LDS afterwards.  NI = 1: K <= 128 (a row has at most 128 entries), NI = 2: up to 256.
+template <int NI>
+__device__ __forceinline__ void ring_issue_facrow(const WLds &L, int slot, int r, const unsigned (&vo)[NI]) {
+    const int lane = lane_id();
+    const double *src = uni_ptr(L.F.LR + (size_t)(r - 64) * LR_STRIDE);
+#pragma unroll
+    for (int m = 0; m < NI; ++m) {
+        const unsigned off = (128 * m + 2 * lane < r) ? vo[m] : ROW_ZERO_OFF;  // (this lane's columns: 128 m + 2 lane, + 1)
+        glds16_s(src, off, L.ringAddr + (unsigned)(slot * NI + m) * 1024u);
+    }
+}
+template <int NI, int TB>
+__device__ __forceinline__ void ring_read_facrow(const WLds &L, int r, double (&l)[NSL]) {
+    constexpr int D = RING_BYTES / (1024 * NI);
+    const int lane = lane_id();
+    const double *__restrict__ slot = L.ring + (size_t)(r % D) * (128 * NI);
+#pragma unroll
+    for (int t = 0; t <= TB; ++t)
+        if (KSLOT * t < 128 * NI) l[t] = slot[KSLOT * t + lane];
+}
 template <int SL, int NI>
-__device__ __forceinline__ void back_sweep_cols(const WLds &L, int Kin, double (&v)[NSL]) {
-    constexpr int D = RING_BYTES / (1024 * NI);   // ring slots; a block of four columns takes four of them
-    constexpr int DB = D / 4;                     // blocks in the ring
+__device__ __forceinline__ void back_sweep_rows(const WLds &L, int Kin, double (&v)[NSL]) {
+    constexpr int D = RING_BYTES / (1024 * NI), DB = D / 4;
     const int lane = lane_id();
     const int K = uni(Kin);
     if (K <= 1) return;
-    const int nb = ((K - 1) >> 2) + 1;            // blocks, processed from the last one down
-    unsigned vo[NI];
-    faccol_offsets<NI>(K, vo);
-    for (int b = nb - 1; b > nb - 1 - DB && b >= 0; --b)
+    if (K > 64) {
+        const int nb = ((K - 1) >> 2) + 1;  // blocks of four rows; blocks 16 .. nb - 1 hold the rows >= 64 (rows >= K: zeros)
+        unsigned vo[NI];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) ring_issue_faccol<NI, true>(L, (4 * b + u) % D, 4 * b + u, vo);
-    double lc[4][NSL], ln[4][NSL];
+        for (int m = 0; m < NI; ++m) vo[m] = (unsigned)(128 * m + 2 * lane) * 8u;
+        for (int b = nb - 1; b > nb - 1 - DB && b >= 16; --b)
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u) ring_issue_facrow<NI>(L, (4 * b + u) % D, 4 * b + u, vo);
+        double lc[4][NSL], ln[4][NSL];
 #pragma unroll
-        for (int t = 0; t < NSL; ++t) lc[u][t] = ln[u][t] = 0.0;
-    wait_all_landed();
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) ring_read_faccol<SL, NI, 0>(L, K, 4 * (nb - 1) + u, lc[u]);
-    wait_lds();
-    // written out once per register slot the block lies in (descending), like the forward sweep: block b sits in
-    // registers, its ring slots take the block DB below, the block below comes out of LDS while this one is summed
-    sfor<0, SL>(SFOR_BODY(tq) {
-        SFOR_IDX(tq);
-        constexpr int tb = SL - 1 - tq;
-        const int bTop = (16 * (tb + 1) < nb ? 16 * (tb + 1) : nb) - 1;
-        for (int b = bTop; b >= 16 * tb; --b) {
-            const int c0 = 4 * b;
-            if (b - DB >= 0) {
+            for (int t = 0; t < NSL; ++t) lc[u][t] = ln[u][t] = 0.0;
+        wait_all_landed();
 #pragma unroll
-                for (int u = 0; u < 4; ++u) ring_issue_faccol<NI, true>(L, (c0 + u) % D, 4 * (b - DB) + u, vo);
-            }
-            if (b > 0) {
-                if (b - DB >= 0) wait_vm<NI * (D - 4)>();  // (blocks b - 2 .. b - DB stay in flight)
-                else wait_vm<0>();
-                // (the block below lies in the slot below when this is the slot's last block)
+        for (int u = 0; u < 4; ++u) ring_read_facrow<NI, SL - 1>(L, 4 * (nb - 1) + u, lc[u]);
+        wait_lds();
+        sfor<0, SL - 1>(SFOR_BODY(tq) {
+            SFOR_IDX(tq);
+            constexpr int tb = SL - 1 - tq;  // SL - 1 .. 1: the slot the block's rows lie in
+            const int bTop = (16 * (tb + 1) < nb ? 16 * (tb + 1) : nb) - 1;
+            for (int b = bTop; b >= 16 * tb; --b) {
+                const int c0 = 4 * b;
+                // block b sits in registers (its reads have completed): its ring slots take the block DB below
+                if (b - DB >= 16) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (b > 16 * tb) ring_read_faccol<SL, NI, tb>(L, K, c0 - 4 + u, ln[u]);  // (uniform)
-                    else ring_read_faccol<SL, NI, (tb > 0 ? tb - 1 : 0)>(L, K, c0 - 4 + u, ln[u]);
+                    for (int u = 0; u < 4; ++u) ring_issue_facrow<NI>(L, (c0 + u) % D, 4 * (b - DB) + u, vo);
                 }
+                if (b > 16) {  // the block below comes out of LDS while this one is applied
+                    if (b - DB >= 16) wait_vm<NI * (D - 4)>();  // (blocks b - 2 .. b - DB stay in flight)
+                    else wait_vm<0>();
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) ring_read_facrow<NI, tb>(L, c0 - 4 + u, ln[u]);
+                }
+                const int l0 = c0 & 63;
+#pragma unroll
+                for (int u = 3; u >= 0; --u) {
+                    const double xr = readlane_f64(v[tb], l0 + u);  // (final: every row beyond has been applied)
+#pragma unroll
+                    for (int t = 0; t <= tb; ++t) v[t] = fma(-lc[u][t], xr, v[t]);  // (zeros from column r on)
+                }
+                wait_lds();
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t <= tb; ++t) lc[u][t] = ln[u][t];
             }
-            // partial sums over the rows beyond the block (x final there); the block's own rows are masked out
-            double prod[4], sums[4];
+        });
+    }
+    // rows 63 .. 1: a gathered row of the packed columns in LDS, four rows per round
+    const int K0 = K < 64 ? K : 64;
+    auto rowT = [&](int r) -> double {  // L(r, c) for c = lane < r, else 0
+        const bool live = lane < r;
+        const double x = L.F.L0[live ? cofs64(lane) - lane + r : L.zidx];
+        return x;
+    };
+    double rc[4], rn[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                double sacc = (lane + KSLOT * tb >= c0 + 4) ? lc[u][tb] * v[tb] : 0.0;
+    for (int u = 0; u < 4; ++u) rc[u] = rowT(K0 - 1 - u);
+    for (int r0 = K0 - 1; r0 > 0; r0 -= 4) {
 #pragma unroll
-                for (int t = tb + 1; t < SL; ++t) sacc = fma(lc[u][t], v[t], sacc);  // (lc is zero for rows >= K)
-                prod[u] = sacc;
-            }
-            wave_sum_multi<4>(prod, sums);
-            const int l0 = c0 & 63;
-            double xb[4];
+        for (int u = 0; u < 4; ++u) rn[u] = rowT(r0 - 4 - u);
 #pragma unroll
-            for (int u = 3; u >= 0; --u) {
-                double x = readlane_f64(v[tb], l0 + u) - sums[u];
-#pragma unroll
-                for (int w = 3; w > u; --w) x = fma(-readlane_f64(lc[u][tb], l0 + w), xb[w], x);  // L(c0+w, c0+u)
-                xb[u] = x;  // (rows >= K: v and lc are zero there, x stays 0)
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[tb] = (lane == l0 + u) ? xb[u] : v[tb];
-            wait_lds();
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int t = (tb > 0 ? tb - 1 : 0); t < SL; ++t) lc[u][t] = ln[u][t];
+        for (int u = 0; u < 4; ++u) {
+            const double xr = readlane_f64(v[0], (r0 - u) & 63);  // (rows <= 0: nothing live, the product is zero)
+            v[0] = fma(-rc[u], xr, v[0]);
         }
-    });
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rc[u] = rn[u];
+    }
 }
 
 // ------------------------------------------------------------------ getRowsGJr (utils.jl:49-86) in registers
@@ -1370,7 +1533,13 @@ __device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p
         rdold[t] = R.rd[t];
         dgold[t] = R.dg[t];
     }
-    delete_update<SL>(L.F, R, K, p, pv, bt);
+    constexpr bool STREAM = NSL > 2 && SL >= 2;  // (big-factor build: update and compaction in one streamed pass)
+    if (STREAM) {
+        if (K <= 192) delete_stream<SL, 1>(L, R, K, p, pv, bt);
+        else delete_stream<SL, 2>(L, R, K, p, pv, bt);
+    } else {
+        delete_update<SL>(L.F, R, K, p, pv, bt);
+    }
     if (downdate) {
         // H' = H - g g' / m,  g = [A;G c']' V_FF^-1 e_p = Y' D^-1 f,  m = (V_FF^-1)_pp = f' D^-1 f,
         // f = L^-1 e_p: f_p = 1, f_r = -p_r below (p = L33^-1 l, the vector the rank-1 update walks through)
@@ -1412,7 +1581,7 @@ __device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p
         gg_rank1(L, -1.0);
         wave_sync();
     }
-    delete_compact<SL>(L.F, K, p);
+    if (!STREAM) delete_compact<SL>(L.F, K, p);
     // per-row registers: rows above p move up
     const int rp = rbcast_i<SL>(R.rank, p);
     shift_up_i<SL>(R.ord, p);
@@ -1752,10 +1921,10 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
         v[t] = (r < K) ? v[t] * R.rd[t] : 0.0;
     }
     if (NSL > 2 && SL >= 2) {  // (rows >= 64 in global memory: by columns, streamed through the ring)
-        if (K <= 192) back_sweep_cols<SL, 1>(L, K, v);
-        else back_sweep_cols<SL, 2>(L, K, v);
+        if (K <= 128) back_sweep_rows<SL, 1>(L, K, v);
+        else back_sweep_rows<SL, 2>(L, K, v);
         // (the factor's global part, rows max(64, c + 1) .. K - 1 of every column: read once here, once by the append)
-        C.sRead += 8ll * ((long long)(K - 64) * 64 + (long long)(K - 64) * (K - 65) / 2);
+        if (K > 64) C.sRead += 8ll * ((long long)(K - 64) * 64 + (long long)(K - 64) * (K - 65) / 2);
     } else {
         back_sweep<SL>(L.F, K, v);
     }
@@ -2218,7 +2387,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
         S.blkDz = 0.0;
         if (S.K > 0) {
             const unsigned cols = ((1u << MJ) - 1u) | (1u << CC);
-            border_sweep<SL>(L.F, R, S.K, cols, C.Ct, C.N, S.hq);
+            border_sweep<SL>(L.F, R, S.K, cols, C.Ct, C.N, S.hq, &L);
             if (!single) recompute_H_all<SL>(L, R, S.K, MJ);
             else if (S.cDirty) recompute_H_c<SL>(L, R, S.K, MJ);
             S.cDirty = false;
@@ -2236,7 +2405,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
             if (S.appJ >= 0 && S.relDz != 0.0) {
                 dzFold = S.relDz;  // ... by the released variable's column only: folded into its append
             } else {
-                border_sweep<SL>(L.F, R, S.K, 1u << CC, C.Ct, C.N, S.hq);
+                border_sweep<SL>(L.F, R, S.K, 1u << CC, C.Ct, C.N, S.hq, &L);
                 recompute_H_c<SL>(L, R, S.K, MJ);
             }
         }
@@ -2279,7 +2448,7 @@ __device__ __forceinline__ int wave_sync_factor(WCtx &C, const WLds &L, WState &
             }
         }
     } else if (S.cDirty && S.K > 0) {  // only hq changed (cannot happen without a change of F today; kept for safety)
-        border_sweep<SL>(L.F, R, S.K, 1u << CC, C.Ct, C.N, S.hq);
+        border_sweep<SL>(L.F, R, S.K, 1u << CC, C.Ct, C.N, S.hq, &L);
         recompute_H_c<SL>(L, R, S.K, MJ);
         S.cDirty = false;
     }
@@ -2395,6 +2564,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     if (PARK) slot1_store(S.R, park);
     if (NSL > 2) {  // the factor's global part starts all zero and stays zero outside the factor (ring_issue_faccol)
         for (int e = lane; e < 256 * 192; e += 64) L.F.L1[e] = 0.0;
+        for (int e = lane; e < 192 * LR_STRIDE; e += 64) L.F.LR[e] = 0.0;
     }
     for (int e = lane; e < NR * NR; e += 64) L.H[e] = 0.0;
     for (int e = lane; e < MJX * MJX; e += 64) L.GG[e] = 0.0;
@@ -2618,9 +2788,11 @@ __global__ __launch_bounds__(64, WPS) void ssqp_wave_kernel(SolveParams P) {
         const int rc = P.waveRC;
         int o = 0;
         L.F.L0 = d0 + o; o += 2080;
+        L.F.LR = nullptr;
         if (NSL > 2) {  // least-squares scratch for up to 256 rows, then rows 64..255 of up to 256 columns
             L.F.L1 = gscr + WAVE_LS_DOUBLES_BIG;
             L.F.R1 = 192;
+            L.F.LR = gscr + WAVE_LS_DOUBLES_BIG + 256 * 192 + 64;
         } else if (PARK) {
             L.F.L1 = gscr + WAVE_LS_DOUBLES;
             L.F.R1 = 64;
@@ -2722,7 +2894,7 @@ int wave_lds_bytes_big() {  // big-factor build: the same without LDS rows >= 64
 size_t wave_scratch_doubles(int variant) {
     // least-squares scratch, then (eight-per-CU build) rows 64..127 of up to 128 columns of the factor and the parked
     // second row slot; (big-factor build) rows 64..255 of up to 256 columns
-    if (variant == 2) return (size_t)WAVE_LS_DOUBLES_BIG + 256 * 192 + 64;
+    if (variant == 2) return (size_t)WAVE_LS_DOUBLES_BIG + 256 * 192 + 64 + 192 * LR_STRIDE + 64;
     return (size_t)WAVE_LS_DOUBLES + 128 * 64 + PARK_FIELDS * 64 + 64;
 }
 hipError_t launch_solve_wave(const SolveParams &P, int grid, int variant, hipStream_t stream) {
