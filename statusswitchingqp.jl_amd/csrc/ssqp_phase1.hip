@@ -174,6 +174,131 @@ __device__ __forceinline__ bool invert_lu(double *a, double *x, int *piv, int n,
     return true;
 }
 
+// The same inversion for n <= LUC by ONE wavefront with the matrix in REGISTERS: lane j holds column j.  As a workgroup
+// every one of the ~3 n dependent steps ends in barriers (some ninety per basis change at n = 11) and an element is a
+// round trip to LDS; here a step of the elimination is: lane k finds the pivot in its own registers and publishes it,
+// every lane swaps its two entries, lane k scales and publishes its column, every lane right of it updates its own --
+// two LDS broadcasts per step, no barrier (a wavefront's LDS operations execute in order; wave_order keeps the compiler
+// from reordering them).  The columns of the inverse then take one lane each: the forward and backward substitution of
+// column c touch only x_c, so lane c runs both in its registers, reading the factors from LDS.  Operations per element
+// and their order exactly as above.  Called by the lanes of the first wavefront; returns false (to all of them) when a
+// pivot is exactly 0.
+constexpr int LUC = 12;
+__device__ __forceinline__ void wave_order() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ bool invert_lu_cols(double *a, double *lbuf, int *piv, int n) {
+    const int j = threadIdx.x & 63;
+    const bool mine = j < n;
+    double col[LUC];
+#pragma unroll
+    for (int i = 0; i < LUC; ++i) col[i] = a[(mine ? j : 0) * n + (i < n ? i : 0)];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < LUC; ++k) {
+        if (k < n && ok) {  // uniform
+            if (j == k) {  // the FIRST largest |a(i, k)|, i = k .. n - 1 (the host's strict ">" scan)
+                int p = k;
+                double best = fabs(col[k]);
+#pragma unroll
+                for (int i = k + 1; i < LUC; ++i)
+                    if (i < n) {
+                        const double v = fabs(col[i]);
+                        if (v > best) best = v, p = i;
+                    }
+                piv[k] = (best == 0.0) ? -1 : p;
+            }
+            wave_order();
+            const int p = piv[k];
+            if (p < 0) {
+                ok = false;
+            } else {
+                if (p != k) {  // rows k and p change places in every column (p > k)
+                    double vp = col[k];
+#pragma unroll
+                    for (int i = k + 1; i < LUC; ++i) vp = (i == p) ? col[i] : vp;
+                    const double vk = col[k];
+                    col[k] = vp;
+#pragma unroll
+                    for (int i = k + 1; i < LUC; ++i) col[i] = (i == p) ? vk : col[i];
+                }
+                if (j == k) {
+                    const double r = 1.0 / col[k];
+#pragma unroll
+                    for (int i = k + 1; i < LUC; ++i)
+                        if (i < n) {
+                            col[i] *= r;
+                            lbuf[i] = col[i];
+                        }
+                }
+                wave_order();
+                double l[LUC];
+#pragma unroll
+                for (int i = k + 1; i < LUC; ++i) l[i] = lbuf[i < n ? i : k + 1 < n ? k + 1 : 0];  // (read together)
+                if (mine && j > k) {
+                    const double akj = col[k];
+#pragma unroll
+                    for (int i = k + 1; i < LUC; ++i)
+                        if (i < n) col[i] -= l[i] * akj;
+                }
+                wave_order();
+            }
+        }
+    }
+    if (!ok) return false;
+    if (mine) {
+#pragma unroll
+        for (int i = 0; i < LUC; ++i)
+            if (i < n) a[j * n + i] = col[i];
+    }
+    wave_order();
+    // column j of the inverse: L U x = P e_j
+    int pv[LUC];
+#pragma unroll
+    for (int k = 0; k < LUC; ++k) pv[k] = piv[k < n ? k : 0];
+    int pos = j;
+#pragma unroll
+    for (int k = 0; k < LUC; ++k)
+        if (k < n && pv[k] != k) pos = (pos == k) ? pv[k] : ((pos == pv[k]) ? k : pos);
+    double xc[LUC];
+#pragma unroll
+    for (int i = 0; i < LUC; ++i) xc[i] = (i == pos) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < LUC; ++k) {  // forward: x[i] -= L(i, k) x[k]  for i > k
+        if (k < n) {
+            double l[LUC];
+#pragma unroll
+            for (int i = k + 1; i < LUC; ++i) l[i] = a[k * n + (i < n ? i : k)];
+#pragma unroll
+            for (int i = k + 1; i < LUC; ++i)
+                if (i < n) xc[i] -= l[i] * xc[k];
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < LUC; ++kk) {  // backward: x[k] /= U(k, k), then x[i] -= U(i, k) x[k]  for i < k
+        const int k = LUC - 1 - kk;
+        if (k < n) {
+            double u[LUC];
+#pragma unroll
+            for (int i = 0; i < LUC; ++i)
+                if (i <= k) u[i] = a[k * n + i];
+            xc[k] /= u[k];
+#pragma unroll
+            for (int i = 0; i < LUC; ++i)
+                if (i < k) xc[i] -= u[i] * xc[k];
+        }
+    }
+    wave_order();  // (every lane has read the factors)
+    if (mine) {
+#pragma unroll
+        for (int i = 0; i < LUC; ++i)
+            if (i < n) a[j * n + i] = xc[i];
+    }
+    wave_order();
+    return true;
+}
+
 struct P1Params {
     int nprob, N, M, J;
     const double *A, *G, *b, *g, *d, *u;   // per problem, back to back (A: M x N, G: J x N, column-major)
@@ -317,7 +442,7 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
     __syncthreads();
     // (the column of A1 / of Y a thread works on is pulled into registers first when M0 <= 16: the sums below are
     //  sequential by construction, and with a dependent global load per term each term would cost a cache round trip)
-    constexpr int MC = 16;
+    constexpr int MC = 12;
     // The host keeps Y = invB * A[:, nonbasic] (Simplex.jl:595) and reads it in two places: the pricing (Y[:,k] . c[basis])
     // and the xb sum (Y[:,k] x_k of the nonbasic columns at a nonzero bound).  Here Y[:,k] only ever exists in the
     // registers of the thread that owns column k: the pricing's dot product is formed at once (same order r = 0 .. M0 - 1
@@ -334,9 +459,25 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
             const int row = e < J ? M + e : e - J;
             const double val = e < J ? 1.0 : sgnArt[row];
             double sd = 0.0;
-            for (int r = 0; r < M0; ++r) {
-                const double sr = 0.0 + invB[(size_t)row * M0 + r] * val;
-                sd += sr * acc[r];
+            if (M0 <= MC) {
+                double iv[MC], cb[MC];
+#pragma unroll
+                for (int r = 0; r < MC; ++r) {
+                    const int rr = r < M0 ? r : 0;
+                    iv[r] = invB[row * M0 + rr];
+                    cb[r] = acc[rr];
+                }
+#pragma unroll
+                for (int r = 0; r < MC; ++r)
+                    if (r < M0) {
+                        const double sr = 0.0 + iv[r] * val;
+                        sd += sr * cb[r];
+                    }
+            } else {
+                for (int r = 0; r < M0; ++r) {
+                    const double sr = 0.0 + invB[(size_t)row * M0 + r] * val;
+                    sd += sr * acc[r];
+                }
             }
             sdot[k] = sd;
         }
@@ -349,12 +490,27 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
                 double av[MC];
 #pragma unroll
                 for (int t = 0; t < MC; ++t) av[t] = (t < M0) ? ak[(size_t)t * N1] : 0.0;
-                for (int r = 0; r < M0; ++r) {
-                    double s = 0.0;
+                // (the M0 entries of invB a sum needs are read TOGETHER, from clamped addresses -- a read under the
+                //  "t < M0" guard waits for its own round trip, eleven in a row -- and two sums are formed side by side)
+                for (int r = 0; r < M0; r += 2) {
+                    const int r1 = r + 1 < M0 ? r + 1 : r;
+                    double iv0[MC], iv1[MC];
+#pragma unroll
+                    for (int t = 0; t < MC; ++t) {
+                        const int tt = t < M0 ? t : 0;
+                        iv0[t] = invB[tt * M0 + r];
+                        iv1[t] = invB[tt * M0 + r1];
+                    }
+                    const double a0 = acc[r], a1 = acc[r1];
+                    double s0 = 0.0, s1 = 0.0;
 #pragma unroll
                     for (int t = 0; t < MC; ++t)
-                        if (t < M0) s += invB[(size_t)t * M0 + r] * av[t];
-                    sd += s * acc[r];
+                        if (t < M0) {
+                            s0 += iv0[t] * av[t];
+                            s1 += iv1[t] * av[t];
+                        }
+                    sd += s0 * a0;
+                    if (r + 1 < M0) sd += s1 * a1;
                 }
             } else {
                 // (four rows at a time: the four sums are independent chains, each in the host's order over t)
@@ -416,13 +572,43 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
         const double *ak = A1 + k;  // (entry t of column k: ak[t * N1])
         for (int r = tid; r < M0; r += NT1) {
             double s = 0.0;
-            for (int t = 0; t < M0; ++t) s += invB[(size_t)t * M0 + r] * ak[(size_t)t * N1];
+            if (M0 <= MC) {  // (the column's entries and the row of invB are requested together: one round trip)
+                double av[MC], iv[MC];
+#pragma unroll
+                for (int t = 0; t < MC; ++t) {
+                    const int tt = t < M0 ? t : 0;
+                    av[t] = ak[(size_t)tt * N1];
+                    iv[t] = invB[tt * M0 + r];
+                }
+#pragma unroll
+                for (int t = 0; t < MC; ++t)
+                    if (t < M0) s += iv[t] * av[t];
+            } else {
+                for (int t = 0; t < M0; ++t) s += invB[(size_t)t * M0 + r] * ak[(size_t)t * N1];
+            }
             pv[r] = s;
         }
-        if (tid < M0) {  // bounds of the basic variables, for the sequential test below (one round trip instead of M0)
-            const int i = basis[tid];
-            blo[tid] = lo[i];
-            bhi[tid] = hi[i];
+        {   // the candidate ratio of every basic row by the thread that formed its pv (the host's expression, so the same
+            // bits); thread 0 then only SELECTS in row order -- no division and no memory round trip in its chain
+            const bool fromLower = S1[k] == SSQP_DN;
+            if (tid < M0) {
+                const int i = basis[tid];
+                const double bl = lo[i], bh = hi[i];
+                const double p = pv[tid];  // (written by this thread above)
+                const bool pos = p > tol, neg = p < -tol;
+                const bool toLower = fromLower ? pos : neg;
+                blo[tid] = (pos || neg) ? (xb[tid] - (toLower ? bl : bh)) / p : 0.0;
+                piv[tid] = (pos || neg) ? (toLower ? 1 : 2) : 0;
+                acc[tid] = bl;  // (the bounds of the basic variables by row: the leaving one's new value is one of them)
+                bhi[tid] = bh;
+            }
+        }
+        // (what thread 0 needs of the entering column after the barrier, requested before it)
+        double hiK = 0.0, loK = 0.0, rangeK = 0.0;
+        if (tid == 0) {
+            hiK = hi[k];
+            loK = lo[k];
+            rangeK = range[k];
         }
         __syncthreads();
         P1_STAMP(3);  // entering column
@@ -431,23 +617,35 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
             int m = 0, li = -1;
             double lr = 0.0;
             int lrow = 0, lto = SSQP_DN;
-            for (int j = 0; j < M0; ++j) {
-                const bool pos = pv[j] > tol, neg = pv[j] < -tol;
-                if (!pos && !neg) continue;
-                const bool toLower = fromLower ? pos : neg;
-                const double ratio = (xb[j] - (toLower ? blo[j] : bhi[j])) / pv[j];
+            auto consider = [&](int j, int code, double ratio) {
+                if (code == 0) return;
                 const bool better = (m == 0) || (fromLower ? (ratio < lr) : (ratio > lr));
-                if (better) lr = ratio, li = m, lrow = j, lto = toLower ? SSQP_DN : SSQP_UP;
+                if (better) lr = ratio, li = m, lrow = j, lto = (code == 1) ? SSQP_DN : SSQP_UP;
                 ++m;
+            };
+            if (M0 <= MC) {
+                double rt[MC];
+                int cd[MC];
+#pragma unroll
+                for (int j = 0; j < MC; ++j) {
+                    const int jj = j < M0 ? j : 0;
+                    rt[j] = blo[jj];
+                    cd[j] = piv[jj];
+                }
+#pragma unroll
+                for (int j = 0; j < MC; ++j)
+                    if (j < M0) consider(j, cd[j], rt[j]);
+            } else {
+                for (int j = 0; j < M0; ++j) consider(j, piv[j], blo[j]);
             }
             int action = 0, leaveStatus = SSQP_DN, st = 0;  // st: 3 = unbounded
             if (fromLower) {
-                const bool finiteUp = hi[k] < INF;
+                const bool finiteUp = hiK < INF;
                 if (m == 0) {
                     if (!finiteUp) st = 3;
                     else action = -1;
                 } else {
-                    if (finiteUp && lr >= range[k]) action = -1;
+                    if (finiteUp && lr >= rangeK) action = -1;
                     else {
                         if (!finiteUp && isinf(lr)) st = 3;
                         else action = lrow + 1, leaveStatus = lto;
@@ -455,10 +653,11 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
                 }
             } else {
                 if (m == 0) action = -2;
-                else if (lr <= -range[k]) action = -2;
+                else if (lr <= -rangeK) action = -2;
                 else action = lrow + 1, leaveStatus = lto;
             }
             (void)li;
+            redv[3] = (leaveStatus == SSQP_DN) ? acc[lrow] : bhi[lrow];  // (a pivot: the bound the leaving variable goes to)
             misc[2] = action;
             misc[3] = leaveStatus;
             misc[1] = st;
@@ -471,9 +670,9 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
         }
         const int action = misc[2];
         if (action == -1) {
-            if (tid == 0) S1[k] = SSQP_UP, x[k] = hi[k];
+            if (tid == 0) S1[k] = SSQP_UP, x[k] = hiK;
         } else if (action == -2) {
-            if (tid == 0) S1[k] = SSQP_DN, x[k] = lo[k];
+            if (tid == 0) S1[k] = SSQP_DN, x[k] = loK;
         } else {
             if (tid == 0) {
                 const int leaving = basis[action - 1];
@@ -496,7 +695,18 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
             __syncthreads();
             P1_STAMP(5);  // basis sort + gather
             P1_COUNT(15);
-            if (!invert_lu(invB, Bm, piv, M0, &misc[1])) {  // lu() of the reference throws (Simplex.jl:590)
+            bool okLu;
+            if (M0 <= LUC) {  // (one wavefront, the matrix in registers; the others wait for its verdict)
+                if (tid < 64) {
+                    const bool okw = invert_lu_cols(invB, Bm, piv, M0);
+                    if (tid == 0) misc[1] = okw ? 1 : 0;
+                }
+                __syncthreads();
+                okLu = misc[1] != 0;
+            } else {
+                okLu = invert_lu(invB, Bm, piv, M0, &misc[1]);
+            }
+            if (!okLu) {  // lu() of the reference throws (Simplex.jl:590)
                 status = -1;
                 break;
             }
@@ -504,7 +714,7 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
                 const int leaving = misc[6], leaveStatus = misc[3];
                 S1[k] = SSQP_IN;
                 S1[leaving] = leaveStatus;
-                x[leaving] = leaveStatus == SSQP_DN ? lo[leaving] : hi[leaving];
+                x[leaving] = redv[3];
             }
             P1_STAMP(6);  // inv(lu(B))
             refreshY();
@@ -524,17 +734,51 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
                     const int t = e / M0, r = e - t * M0;
                     const int kk = list[t0 + t];
                     double y = 0.0;  // Y[r, kk] = (invB * A1[:, kk])_r, as refreshY forms it
-                    for (int t2 = 0; t2 < M0; ++t2) y += invB[(size_t)t2 * M0 + r] * A1[(size_t)t2 * N1 + kk];
+                    if (M0 <= MC) {
+                        double av[MC], iv[MC];
+#pragma unroll
+                        for (int t2 = 0; t2 < MC; ++t2) {
+                            const int tt = t2 < M0 ? t2 : 0;
+                            av[t2] = A1[(size_t)tt * N1 + kk];
+                            iv[t2] = invB[tt * M0 + r];
+                        }
+#pragma unroll
+                        for (int t2 = 0; t2 < MC; ++t2)
+                            if (t2 < M0) y += iv[t2] * av[t2];
+                    } else {
+                        for (int t2 = 0; t2 < M0; ++t2) y += invB[(size_t)t2 * M0 + r] * A1[(size_t)t2 * N1 + kk];
+                    }
                     terms[(size_t)t * M0 + r] = y * x[kk];
                 }
                 __syncthreads();
-                if (tid < M0)
-                    for (int t = 0; t < nt; ++t) a2 += terms[(size_t)t * M0 + tid];
+                if (tid < M0) {  // (eight terms per LDS round trip, added in order)
+                    for (int t0b = 0; t0b < nt; t0b += 8) {
+                        double tv[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) tv[q] = terms[(size_t)(t0b + q < nt ? t0b + q : t0b) * M0 + tid];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if (t0b + q < nt) a2 += tv[q];
+                    }
+                }
                 __syncthreads();
             }
             for (int r = tid; r < M0; r += NT1) {
                 double s = 0.0;
-                for (int t = 0; t < M0; ++t) s += invB[(size_t)t * M0 + r] * rhs[t];
+                if (M0 <= MC) {
+                    double iv[MC], rv[MC];
+#pragma unroll
+                    for (int t = 0; t < MC; ++t) {
+                        const int tt = t < M0 ? t : 0;
+                        iv[t] = invB[tt * M0 + r];
+                        rv[t] = rhs[tt];
+                    }
+#pragma unroll
+                    for (int t = 0; t < MC; ++t)
+                        if (t < M0) s += iv[t] * rv[t];
+                } else {
+                    for (int t = 0; t < M0; ++t) s += invB[(size_t)t * M0 + r] * rhs[t];
+                }
                 xb[r] = s - a2;
             }
             __syncthreads();

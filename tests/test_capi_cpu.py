@@ -104,3 +104,40 @@ def test_qp_constructor_mirrors_reference(pkg):
     with pytest.raises(TypeError):
         pkg.Settings(bogus=1)                                                                    # MOIwrapper.jl:17-31
     assert [int(s) for s in (pkg.IN, pkg.DN, pkg.UP, pkg.OE, pkg.EO)] == [0, 1, 2, 3, 4]        # types.jl:17-23
+
+
+def test_m0_belongs_to_the_lds_dma_loads():
+    """The LDS-DMA loads of the big-factor build (glds16_s in ssqp_wave.hip) set M0 and do not restore it: nothing else in
+    the library's kernels may use M0.  Checked on the code objects of the built device objects."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    objs = [o for o in sorted(glob.glob(os.path.join(ROOT, "statusswitchingqp.jl_amd", "csrc", "ssqp_*.o")))
+            if "_prof" not in o and not o.endswith("ssqp_host.o")]
+    if not (objs and os.path.exists(os.path.join(llvm, "llvm-objdump"))):
+        pytest.skip("no built objects / no llvm tools")
+    n_dma = n_load = 0
+    tmp = tempfile.mkdtemp()
+    try:
+        for o in objs:
+            fb, co = os.path.join(tmp, "fb.bin"), os.path.join(tmp, "dev.co")
+            subprocess.run([f"{llvm}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", o, fb], check=True)
+            un = subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fb}",
+                                 "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], capture_output=True)
+            if un.returncode != 0:
+                continue  # (an object without device code)
+            dis = subprocess.run([f"{llvm}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+            ins = [ln.split("//")[0].strip() for ln in dis.splitlines() if "//" in ln]
+            for i, s in enumerate(ins):
+                if s.startswith("global_load_lds_dwordx4"):
+                    n_load += 1
+                if not re.search(r"\bm0\b", s):
+                    continue
+                assert re.fullmatch(r"s_mov_b32 m0, s\d+", s), (o, s)
+                assert ins[i + 1].startswith("s_nop") and ins[i + 2].startswith("global_load_lds_dwordx4"), (o, ins[i:i + 3])
+                n_dma += 1
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    assert n_dma == n_load > 0
