@@ -84,12 +84,19 @@ __device__ __forceinline__ int compact_columns(int n, int *list, int *cnt, Pred 
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         int base = 0;
-        for (int c0 = 0; c0 < n; c0 += 64) {
-            const int k = c0 + lane;
-            const bool f = (k < n) && pred(k);
-            const unsigned long long m = __ballot(f);
-            if (f) list[base + __popcll(m & ((1ull << lane) - 1ull))] = k;
-            base += __popcll(m);
+        for (int cb = 0; cb < n; cb += 512) {  // (eight chunks' flags are read together: their reads do not wait for the list's writes)
+            bool f[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = cb + 64 * q + lane;
+                f[q] = (k < n) && pred(k);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const unsigned long long m = __ballot(f[q]);
+                if (f[q]) list[base + __popcll(m & ((1ull << lane) - 1ull))] = cb + 64 * q + lane;
+                base += __popcll(m);
+            }
         }
         if (lane == 0) *cnt = base;
     }
@@ -680,6 +687,26 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
                 nonbasic[k] = 0;
                 nonbasic[leaving] = 1;
                 basis[action - 1] = k;
+                if (M0 <= MC) {  // sort(basis) in registers (the basis was sorted before the exchange: one pass each way)
+                    int bs[MC];
+#pragma unroll
+                    for (int a2 = 0; a2 < MC; ++a2) bs[a2] = (a2 < M0) ? basis[a2 < M0 ? a2 : 0] : 0x7fffffff;
+#pragma unroll
+                    for (int a2 = 0; a2 + 1 < MC; ++a2) {  // the new entry sinks up ...
+                        const int lo2 = min(bs[a2], bs[a2 + 1]), hi2 = max(bs[a2], bs[a2 + 1]);
+                        bs[a2] = lo2;
+                        bs[a2 + 1] = hi2;
+                    }
+#pragma unroll
+                    for (int a2 = MC - 2; a2 >= 0; --a2) {  // ... or down
+                        const int lo2 = min(bs[a2], bs[a2 + 1]), hi2 = max(bs[a2], bs[a2 + 1]);
+                        bs[a2] = lo2;
+                        bs[a2 + 1] = hi2;
+                    }
+#pragma unroll
+                    for (int a2 = 0; a2 < MC; ++a2)
+                        if (a2 < M0) basis[a2] = bs[a2];
+                } else
                 for (int a2 = 1; a2 < M0; ++a2) {  // sort(basis)
                     const int v = basis[a2];
                     int c2 = a2 - 1;
@@ -730,8 +757,18 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
             double a2 = 0.0;
             for (int t0 = 0; t0 < cnt; t0 += XB_CHUNK) {
                 const int nt = cnt - t0 < XB_CHUNK ? cnt - t0 : XB_CHUNK;
-                for (int e = tid; e < nt * M0; e += NT1) {
-                    const int t = e / M0, r = e - t * M0;
+                // (M0 <= 16: thread -> (column t = tid / 16 + 16 i, row r = tid % 16), no integer division per element)
+                const int eStep = M0 <= 16 ? 16 : NT1, eEnd = M0 <= 16 ? nt : nt * M0;
+                for (int e = M0 <= 16 ? (tid >> 4) : tid; e < eEnd; e += eStep) {
+                    int t, r;
+                    if (M0 <= 16) {
+                        t = e;
+                        r = tid & 15;
+                        if (r >= M0) break;
+                    } else {
+                        t = e / M0;
+                        r = e - t * M0;
+                    }
                     const int kk = list[t0 + t];
                     double y = 0.0;  // Y[r, kk] = (invB * A1[:, kk])_r, as refreshY forms it
                     if (M0 <= MC) {
