@@ -20,6 +20,7 @@
 
 #include "ssqp_hip.h"
 #include "ssqp_internal.h"
+#include "ssqp_device.h"
 
 namespace ssqp {
 namespace p1 {
@@ -41,7 +42,7 @@ static __device__ unsigned long long g_p1phase[16];
 #define P1_COUNT(slot) p1a[slot] += 1
 #define P1_FLUSH()                                                                                                     \
     do {                                                                                                               \
-        if (threadIdx.x == 0)                                                                                          \
+        if (tid == 0)                                                                                                  \
             for (int k_ = 0; k_ < 16; ++k_)                                                                            \
                 (void)__hip_atomic_fetch_add(&g_p1phase[k_], p1a[k_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     \
     } while (0)
@@ -55,12 +56,10 @@ static __device__ unsigned long long g_p1phase[16];
 // block-wide (value, index) maximum with the FIRST maximum winning (smallest index on ties); all threads get it
 __device__ __forceinline__ void block_first_max(double &v, int &idx, double *rv, int *ri) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(v, off);
-        const int oi = __shfl_xor(idx, off);
-        const bool take = (ov > v) || (ov == v && oi < idx);
-        v = take ? ov : v;
-        idx = take ? oi : idx;
+    {   // inside the wavefront: DPP steps (the first maximum of v = the first minimum of -v)
+        const KeyMin km = wave_keymin(KeyMin{-v, idx});
+        v = -km.v;
+        idx = km.ord;
     }
     if (lane == 0) {
         rv[wave] = v;
@@ -80,9 +79,9 @@ __device__ __forceinline__ void block_first_max(double &v, int &idx, double *rv,
 // ascending list of the columns k < n with pred(k): one wavefront scans in chunks of 64 (ballot + popcount keeps
 // the order); returns the count to every thread through *cnt (LDS)
 template <class Pred>
-__device__ __forceinline__ int compact_columns(int n, int *list, int *cnt, Pred pred) {
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
+__device__ __forceinline__ int compact_columns(int tid, int n, int *list, int *cnt, Pred pred) {
+    if (tid < 64) {
+        const int lane = tid;
         int base = 0;
         for (int cb = 0; cb < n; cb += 512) {  // (eight chunks' flags are read together: their reads do not wait for the list's writes)
             bool f[8];
@@ -106,8 +105,7 @@ __device__ __forceinline__ int compact_columns(int n, int *list, int *cnt, Pred 
 
 // inv(lu(a)) in place for the n x n column-major LDS matrix a (scratch x: n x n), partial pivoting, the host's
 // operation order per element (ssqp_host.cpp invert_lu).  Returns false when a pivot is exactly 0.
-__device__ __forceinline__ bool invert_lu(double *a, double *x, int *piv, int n, int *flag) {
-    const int tid = threadIdx.x;
+__device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, int *piv, int n, int *flag) {
     for (int k = 0; k < n; ++k) {
         if (tid == 0) {
             int p = k;
@@ -355,8 +353,8 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
     // ---- free / upper-only variables (SSQP.jl:484-509), ascending lists
     int *iw = P.wsInt + (size_t)prob * P.wsIntStride;
     int *freeVars = iw, *upperOnly = iw + N;
-    const int nfree = compact_columns(N, freeVars, &misc[4], [&](int k) { return u[k] == INF && d[k] == -INF; });
-    const int nup = compact_columns(N, upperOnly, &misc[5], [&](int k) { return !(u[k] == INF && d[k] == -INF) && d[k] == -INF; });
+    const int nfree = compact_columns(tid, N, freeVars, &misc[4], [&](int k) { return u[k] == INF && d[k] == -INF; });
+    const int nup = compact_columns(tid, N, upperOnly, &misc[5], [&](int k) { return !(u[k] == INF && d[k] == -INF) && d[k] == -INF; });
     const int N0 = N + J + nfree, N1 = N0 + M0;
     int32_t *S1 = iw + 2 * N;
     int *nonbasic = S1 + N1;
@@ -412,7 +410,7 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
     __syncthreads();
     // start = sum over the columns with lo != 0, ascending, of A1[:,k] * lo[k]
     {
-        const int cnt = compact_columns(N0, list, &misc[0], [&](int k) { return lo[k] != 0.0; });
+        const int cnt = compact_columns(tid, N0, list, &misc[0], [&](int k) { return lo[k] != 0.0; });
         for (int r = tid; r < M0; r += NT1) {
             double s = 0.0;
             for (int t = 0; t < cnt; ++t) {
@@ -488,38 +486,48 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
             }
             sdot[k] = sd;
         }
-        for (int k = tid; k < N1; k += NT1) {
-            if (k >= N && (k < N + J || k >= N0)) continue;  // (unit columns: done above)
-            if (!nonbasic[k]) continue;
-            const double *ak = A1 + k;  // (entry t of column k: ak[t * N1])
-            double sd = 0.0;
-            if (M0 <= MC) {
-                double av[MC];
+        auto general = [&](int k) { return k < N1 && !(k >= N && (k < N + J || k >= N0)); };  // (unit columns: done above)
+        if (M0 <= MC) {
+            // two columns per thread and round (k, k + NT1): the entries of invB a row's sums need are read ONCE for both --
+            // LDS reads, not arithmetic, are what sixteen wavefronts per CU queue for here -- and TOGETHER, from clamped
+            // addresses (a read under the "t < M0" guard waits for its own round trip, eleven in a row)
+            for (int k = tid; k < N1; k += 2 * NT1) {
+                const int kb = k + NT1;
+                const bool doA = general(k) && nonbasic[k], doB = general(kb) && nonbasic[kb < N1 ? kb : k];
+                if (!doA && !doB) continue;
+                const double *akA = A1 + (doA ? k : kb), *akB = A1 + (doB ? kb : k);  // (entry t of a column: ak[t * N1])
+                double avA[MC], avB[MC];
 #pragma unroll
-                for (int t = 0; t < MC; ++t) av[t] = (t < M0) ? ak[(size_t)t * N1] : 0.0;
-                // (the M0 entries of invB a sum needs are read TOGETHER, from clamped addresses -- a read under the
-                //  "t < M0" guard waits for its own round trip, eleven in a row -- and two sums are formed side by side)
-                for (int r = 0; r < M0; r += 2) {
-                    const int r1 = r + 1 < M0 ? r + 1 : r;
-                    double iv0[MC], iv1[MC];
+                for (int t = 0; t < MC; ++t) {
+                    const size_t o = (size_t)(t < M0 ? t : 0) * N1;
+                    avA[t] = akA[o];
+                    avB[t] = akB[o];
+                }
+                double sdA = 0.0, sdB = 0.0;
+                for (int r = 0; r < M0; ++r) {
+                    double iv[MC];
 #pragma unroll
-                    for (int t = 0; t < MC; ++t) {
-                        const int tt = t < M0 ? t : 0;
-                        iv0[t] = invB[tt * M0 + r];
-                        iv1[t] = invB[tt * M0 + r1];
-                    }
-                    const double a0 = acc[r], a1 = acc[r1];
-                    double s0 = 0.0, s1 = 0.0;
+                    for (int t = 0; t < MC; ++t) iv[t] = invB[(t < M0 ? t : 0) * M0 + r];
+                    const double a0 = acc[r];
+                    double sA = 0.0, sB = 0.0;
 #pragma unroll
                     for (int t = 0; t < MC; ++t)
                         if (t < M0) {
-                            s0 += iv0[t] * av[t];
-                            s1 += iv1[t] * av[t];
+                            sA += iv[t] * avA[t];
+                            sB += iv[t] * avB[t];
                         }
-                    sd += s0 * a0;
-                    if (r + 1 < M0) sd += s1 * a1;
+                    sdA += sA * a0;
+                    sdB += sB * a0;
                 }
-            } else {
+                if (doA) sdot[k] = sdA;
+                if (doB) sdot[kb] = sdB;
+            }
+        } else {
+            for (int k = tid; k < N1; k += NT1) {
+                if (!general(k)) continue;
+                if (!nonbasic[k]) continue;
+                const double *ak = A1 + k;  // (entry t of column k: ak[t * N1])
+                double sd = 0.0;
                 // (four rows at a time: the four sums are independent chains, each in the host's order over t)
                 for (int r0 = 0; r0 < M0; r0 += 4) {
                     double s4[4] = {0.0, 0.0, 0.0, 0.0};
@@ -533,8 +541,8 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
                     for (int u = 0; u < 4; ++u)
                         if (r0 + u < M0) sd += s4[u] * acc[r0 + u];
                 }
+                sdot[k] = sd;
             }
-            sdot[k] = sd;
         }
         __syncthreads();
     };
@@ -731,7 +739,7 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
                 __syncthreads();
                 okLu = misc[1] != 0;
             } else {
-                okLu = invert_lu(invB, Bm, piv, M0, &misc[1]);
+                okLu = invert_lu(tid, invB, Bm, piv, M0, &misc[1]);
             }
             if (!okLu) {  // lu() of the reference throws (Simplex.jl:590)
                 status = -1;
@@ -750,7 +758,7 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
         __syncthreads();
         // xb = invB*b - Y*x[nonbasic]: the nonbasic columns at a nonzero value, ascending
         {
-            const int cnt = compact_columns(N1, list, &misc[0], [&](int kk) { return nonbasic[kk] && x[kk] != 0.0; });
+            const int cnt = compact_columns(tid, N1, list, &misc[0], [&](int kk) { return nonbasic[kk] && x[kk] != 0.0; });
             // the sum runs over the listed columns in ascending order, one rounded multiply and one rounded add per term
             // (the host's order): the PRODUCTS of a chunk of columns are formed by all threads at once (one memory round
             // trip for the chunk instead of one per term), the adds stay in order

@@ -2772,9 +2772,10 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
 //                  (PARK).  Half of the QPs of the headline workload end with 64-79 free variables, but only in their
 //                  last tenth: carrying the second slot's 36 registers through every pass cost this build some 130
 //                  spilled registers and a tenth of its throughput.
-//   2: <1, false> with FOUR row slots (NSL = 4) -- the big-factor build: up to 255 free variables, rows >= 64 of the
-//                  factor in global scratch, back substitution by columns.  It takes the QPs builds 0 / 1 hand over
-//                  (P.resume: problem ids from their hand-over list, start from the (z, S) they left).
+//   2: <1, false> with FOUR row slots (NSL = 4) -- the big-factor build: up to 252 free variables, rows >= 64 of the
+//                  factor in global scratch (by columns for the forward sweep and the delete, by rows for the back
+//                  substitution), every stream through an LDS ring filled by LDS-DMA loads.  It takes the QPs builds
+//                  0 / 1 hand over (P.resume: problem ids from their hand-over list, start from the (z, S) they left).
 // Each hands a QP that outgrows it over to the next stage (0 / 1 -> 2 -> the workgroup kernel).
 template <int WPS, bool PARK, int SLOTS>  // (SLOTS = NSL: part of the kernel's name, so that the builds' kernels differ)
 __global__ __launch_bounds__(64, WPS) void ssqp_wave_kernel(SolveParams P) {
