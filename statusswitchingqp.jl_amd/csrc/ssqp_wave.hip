@@ -549,28 +549,37 @@ __device__ __forceinline__ void fwd_sweep_ring(const WLds &L, int Kin, AP &&ap) 
     sfor<0, SL>(SFOR_BODY(tb) {
         SFOR_IDX(tb);
         const int gEnd = (16 * (tb + 1) < ng) ? 16 * (tb + 1) : ng;
-        for (int g = 16 * tb; g < gEnd; ++g) {
+        // one round: group g sits in `cur` (read a round ago, the reads have completed); its ring slots take the group
+        // D / 4 ahead, the next group's entries come out of LDS into `nxt` while this group is applied
+        auto round = [&](int g, double (&cur)[4][NSL], double (&nxt)[4][NSL]) __attribute__((always_inline)) {
             const int c0 = 4 * g;
-            // group g sits in registers (read a round ago, the reads have completed): its slots take the group D / 4 ahead
             const bool more = c0 + D < 4 * ng;
             if (more) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) ring_issue_faccol<NI, true>(L, (c0 + u) % D, c0 + D + u, vo);
             }
-            if (g + 1 < ng) {  // the next group's entries come out of LDS while this group is applied
+            if (g + 1 < ng) {
                 if (more) wait_vm<NI * (D - 4)>();  // (groups g + 2 .. g + D / 4 stay in flight)
                 else wait_vm<0>();
 #pragma unroll
-                for (int u = 0; u < 4; ++u) ring_read_faccol<SL, NI, tb>(L, K, c0 + 4 + u, ln[u]);
+                for (int u = 0; u < 4; ++u) ring_read_faccol<SL, NI, tb>(L, K, c0 + 4 + u, nxt[u]);
             }
             const int l0 = c0 & 63;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) ap(IC<tb>{}, l0 + u, lc[u]);
-            wait_lds();  // (ln has arrived: the slots of group g + 1 are free for the next round's request)
+            for (int u = 0; u < 4; ++u) ap(IC<tb>{}, l0 + u, cur[u]);
+            wait_lds();  // (nxt has arrived: the slots of group g + 1 are free for the next round's request)
+        };
+        // (two rounds per trip, the two register sets changing roles: no copy between rounds)
+        for (int g = 16 * tb; g < gEnd; g += 2) {
+            round(g, lc, ln);
+            if (g + 1 < gEnd) {
+                round(g + 1, ln, lc);
+            } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int t = tb; t < SL; ++t) lc[u][t] = ln[u][t];
+                    for (int t = 0; t < NSL; ++t) lc[u][t] = ln[u][t];
+            }
         }
     });
 }
@@ -1026,31 +1035,40 @@ __device__ __forceinline__ void back_sweep_rows(const WLds &L, int Kin, double (
             SFOR_IDX(tq);
             constexpr int tb = SL - 1 - tq;  // SL - 1 .. 1: the slot the block's rows lie in
             const int bTop = (16 * (tb + 1) < nb ? 16 * (tb + 1) : nb) - 1;
-            for (int b = bTop; b >= 16 * tb; --b) {
+            // one round: block b sits in `cur` (its reads have completed); its ring slots take the block DB below, the
+            // block below comes out of LDS into `nxt` while this one is applied
+            auto round = [&](int b, double (&cur)[4][NSL], double (&nxt)[4][NSL]) __attribute__((always_inline)) {
                 const int c0 = 4 * b;
-                // block b sits in registers (its reads have completed): its ring slots take the block DB below
                 if (b - DB >= 16) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) ring_issue_facrow<NI>(L, (c0 + u) % D, 4 * (b - DB) + u, vo);
                 }
-                if (b > 16) {  // the block below comes out of LDS while this one is applied
+                if (b > 16) {
                     if (b - DB >= 16) wait_vm<NI * (D - 4)>();  // (blocks b - 2 .. b - DB stay in flight)
                     else wait_vm<0>();
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) ring_read_facrow<NI, tb>(L, c0 - 4 + u, ln[u]);
+                    for (int u = 0; u < 4; ++u) ring_read_facrow<NI, tb>(L, c0 - 4 + u, nxt[u]);
                 }
                 const int l0 = c0 & 63;
 #pragma unroll
                 for (int u = 3; u >= 0; --u) {
                     const double xr = readlane_f64(v[tb], l0 + u);  // (final: every row beyond has been applied)
 #pragma unroll
-                    for (int t = 0; t <= tb; ++t) v[t] = fma(-lc[u][t], xr, v[t]);  // (zeros from column r on)
+                    for (int t = 0; t <= tb; ++t) v[t] = fma(-cur[u][t], xr, v[t]);  // (zeros from column r on)
                 }
                 wait_lds();
+            };
+            // (two rounds per trip, the two register sets changing roles: no copy between rounds)
+            for (int b = bTop; b >= 16 * tb; b -= 2) {
+                round(b, lc, ln);
+                if (b - 1 >= 16 * tb) {
+                    round(b - 1, ln, lc);
+                } else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                    for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int t = 0; t <= tb; ++t) lc[u][t] = ln[u][t];
+                        for (int t = 0; t < NSL; ++t) lc[u][t] = ln[u][t];
+                }
             }
         });
     }

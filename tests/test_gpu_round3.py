@@ -188,9 +188,9 @@ def _oracle_fast(orc, prob, S0, x0):
 
 @pytest.mark.parametrize("family", ["cfg3_like", "blocking", "inequalities", "n512"])
 def test_big_factor_build_families(pkg, orc, family):
-    """free sets of 128..250 rows in the four-row-slot build (rows >= 64 in global scratch, back substitution by
-    columns): appends only (cfg3), upper bounds that block at large K (deletes across the slot boundaries), active
-    inequalities at large K, N = 512.  Reached by hand-over from both first-stage builds and from the first pass."""
+    """free sets of 128..250 rows in the four-row-slot build (rows >= 64 in global scratch by columns and by rows, every
+    stream through the LDS ring): appends only (cfg3), upper bounds that block at large K (streamed deletes across the
+    slot boundaries), active inequalities at large K, N = 512.  Reached by hand-over from both first-stage builds and from the first pass."""
     if family == "cfg3_like":       # K -> ~170, appends almost only
         cfg, n = pkg.GenConfig(200, 1, 0, 400, 1e-3, 0.1, 1.2, 0.0), 24
     elif family == "blocking":      # K -> ~215 with ~60 blocked steps on the way (deletes in every row slot)
