@@ -1413,7 +1413,9 @@ __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int 
     const double uj = C.uhi[j], dj = C.dlo[j];
     const double zj = __hip_atomic_load(zg + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (written by this wavefront earlier)
     double lnew[NSL], vraw[NSL], ysub[NSL];
+    WPH_DECL;
     const double dnew = append_row<SL>(L, R, K, j, C.V, N, lnew, vraw, ysub);
+    WPH(14);  // (inside "one append": the gather of V[F, j], the forward sweep, the new row's stores)
     if (!(dnew > 0.0)) return false;
     if (dz != 0.0) {  // uniform
 #pragma unroll
