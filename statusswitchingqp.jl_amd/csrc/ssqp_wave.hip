@@ -343,6 +343,7 @@ struct WLds {
     const double *ring;
     unsigned ringAddr;  // its LDS byte address (the M0 base of the DMA destination)
     int zidx;           // index (relative to F.L0) of an LDS double that is always zero
+    const double *zero; // the same word as a pointer (every build has one)
 };
 
 // ------------------------------------------------------------------ column streams through an LDS ring (big-factor build)
@@ -1189,26 +1190,40 @@ __device__ __forceinline__ unsigned rank_filter(const Rows &R, double bEv, unsig
 // H[a][b] -= / += over all pairs, three entries per lane
 __device__ __forceinline__ void h_rank1(const WLds &L, double scale) {  // H += scale * yn yn'
     const int lane = lane_id();
+    // (all nine reads first, from clamped addresses: a read inside the "e < NR * NR" branch, or behind the previous
+    //  entry's store, waits for its own LDS round trip)
+    double ya[3], yb[3], h[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int e = lane + 64 * q, ee = e < NR * NR ? e : 0;
+        const int a = ee / NR, b = ee - a * NR;
+        ya[q] = L.yn[a];
+        yb[q] = L.yn[b];
+        h[q] = L.H[ee];
+    }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const int e = lane + 64 * q;
-        if (e < NR * NR) {
-            const int a = e / NR, b = e - a * NR;
-            L.H[e] = fma(L.yn[a] * scale, L.yn[b], L.H[e]);
-        }
+        if (e < NR * NR) L.H[e] = fma(ya[q] * scale, yb[q], h[q]);
     }
 }
 
 // GG += sign * xn xn'  (two entries per lane)
 __device__ __forceinline__ void gg_rank1(const WLds &L, double sign) {
     const int lane = lane_id();
+    double xa[2], xb[2], g[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = lane + 64 * q, ee = e < MJX * MJX ? e : 0;
+        const int a = ee / MJX, b = ee - a * MJX;
+        xa[q] = L.xn[a];
+        xb[q] = L.xn[b];
+        g[q] = L.GG[ee];
+    }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int e = lane + 64 * q;
-        if (e < MJX * MJX) {
-            const int a = e / MJX, b = e - a * MJX;
-            L.GG[e] = fma(L.xn[a] * sign, L.xn[b], L.GG[e]);
-        }
+        if (e < MJX * MJX) L.GG[e] = fma(xa[q] * sign, xb[q], g[q]);
     }
 }
 
@@ -1226,20 +1241,22 @@ template <int WM>
 __device__ __forceinline__ bool full_rank_certified(const WLds &L, int W0, int raLane) {
     const int lane = lane_id();
     const int ri = lane < W0 ? raLane : 0;  // raLane: L.ra[lane], the row id of position `lane`
-    double a[WM];
+    // (an entry that does not exist is read from a zero word of LDS: with a select on the DATA the compiler puts every
+    //  read under its own exec mask and waits for each round trip; here the WM reads go out together)
+    const int zG = (int)(L.zero - L.GG);
+    double a[WM], dgg[WM];
 #pragma unroll
     for (int c = 0; c < WM; ++c) {
         const int rc = __builtin_amdgcn_readlane(raLane, c < W0 ? c : 0);
-        const double v = L.GG[ri * MJX + rc];
-        a[c] = (lane < W0 && c < W0) ? v : 0.0;
+        a[c] = L.GG[(lane < W0 && c < W0) ? ri * MJX + rc : zG];
+        dgg[c] = L.GG[rc * MJX + rc];  // (the diagonal entry the threshold of step c is taken from)
     }
     bool ok = true;
 #pragma unroll
     for (int c = 0; c < WM; ++c) {
         if (c < W0) {  // uniform
             const double d = readlane_f64(a[c], c);
-            const int rc = __builtin_amdgcn_readlane(raLane, c);
-            const double thr = fmax(1e-8, 1e-6 * L.GG[rc * MJX + rc]);
+            const double thr = fmax(1e-8, 1e-6 * dgg[c]);
             if (!(d > thr)) ok = false;
             const double r = fast_rcp(d > thr ? d : 1.0);
             const double lic = a[c] * r;
@@ -1263,12 +1280,12 @@ template <int WM>
 __device__ __forceinline__ bool schur_solve(const WLds &L, double bEv, int W, double &lam, int raLane) {
     const int lane = lane_id();
     const int ri = lane < W ? raLane : 0;  // raLane: L.ra[lane]
+    const int zH = (int)(L.zero - L.H);   // (a zero word of LDS for the entries that do not exist: see full_rank_certified)
     double a[WM];
 #pragma unroll
     for (int c = 0; c < WM; ++c) {
         const int rc = __builtin_amdgcn_readlane(raLane, c < W ? c : 0);
-        const double v = L.H[ri * NR + rc];
-        a[c] = (lane < W && c < W) ? v : 0.0;
+        a[c] = L.H[(lane < W && c < W) ? ri * NR + rc : zH];
     }
     double y = bperm_f64(bEv, ri) + L.H[ri * NR + CC];
     y = (lane < W) ? y : 0.0;
@@ -1995,10 +2012,13 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
         double Ga = 0.0;
         {
             const int wl = lane < MJ ? lane : 0;
+            double hw[MJX];  // (row wl of H read at once: a read under the uniform branch waits for its own round trip)
+#pragma unroll
+            for (int a = 0; a < MJX; ++a) hw[a] = L.H[wl * NR + a];
             Ga = L.H[wl * NR + CC];
 #pragma unroll
             for (int a = 0; a < MJX; ++a)
-                if ((kept >> a) & 1u) Ga = fma(L.H[wl * NR + a], readlane_f64(alRow, a), Ga);  // uniform
+                if ((kept >> a) & 1u) Ga = fma(hw[a], readlane_f64(alRow, a), Ga);  // uniform
             Ga = -Ga;
         }
         const double po = Ga - S.gz, zo = S.bEv - S.gz;
@@ -2833,11 +2853,11 @@ __global__ __launch_bounds__(64, WPS) void ssqp_wave_kernel(SolveParams P) {
         o += 8;
         L.ring = nullptr;
         L.ringAddr = 0u;
-        L.zidx = 0;
+        L.zidx = o;                     // (a double that stays zero: what a masked-out lane of a gather or of the factor sweeps reads)
+        L.zero = d0 + o;
+        if (threadIdx.x == 0) d0[o] = 0.0;
+        o += 2;
         if (NSL > 2) {
-            L.zidx = o;                 // (a double that stays zero: what a masked-out lane of the factor sweeps reads)
-            if (threadIdx.x == 0) d0[o] = 0.0;
-            o += 2;
             o = (o + 127) / 128 * 128;  // (1 KiB alignment of the DMA pieces)
             L.ring = d0 + o;
             // low half of the flat address of an LDS location = its LDS byte address; read through v_readfirstlane so that
@@ -2906,11 +2926,11 @@ bool wave_kernel_applies(int N, int M, int J) {
 int wave_lds_bytes(int rc) {  // rc <= 0: the builds that keep rows >= 64 in global scratch (eight-per-CU, big-factor)
     const int r1 = rc > 64 ? rc - 64 : 0;
     const int l1 = rc > 0 ? rc * r1 + 2 : 0;
-    const int dbl = 2080 + l1 + NR * NR + 2 * (MJX * MJX + 1) + 16 * 3 + 8;
+    const int dbl = 2080 + l1 + NR * NR + 2 * (MJX * MJX + 1) + 16 * 3 + 8 + 2;  // (+ the zero word)
     return dbl * 8;
 }
 int wave_lds_bytes_big() {  // big-factor build: the same without LDS rows >= 64, plus the column ring (1 KiB aligned)
-    return (wave_lds_bytes(0) + 16 + 1023) / 1024 * 1024 + RING_BYTES;  // (+ the zero word)
+    return (wave_lds_bytes(0) + 1023) / 1024 * 1024 + RING_BYTES;
 }
 size_t wave_scratch_doubles(int variant) {
     // least-squares scratch, then (eight-per-CU build) rows 64..127 of up to 128 columns of the factor and the parked
