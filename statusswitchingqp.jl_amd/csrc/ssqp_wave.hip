@@ -1361,9 +1361,9 @@ enum { W_CONTINUE = 0, W_BREAK = 1, W_HANDOVER = 2 };
 // every dense vector / status update that follows a change of z[j] of a BOUND variable by dz (it entered B at a
 // nonzero value, or leaves B): hq += V[:,j] dz, bEall -= [A;G][:,j] dz  (the caches of SSQP.jl:295,324)
 __device__ __forceinline__ void bound_shift(const WCtx &C, double2 (&hq)[NCH], double &bEv, int j, double dz) {
-    axpy_dense(hq, C.V + (size_t)j * C.N, dz, C.N);
     const int lane = lane_id();
-    const double cj = C.Ct[(size_t)(lane < C.MJ ? lane : 0) * C.N + j];
+    const double cj = C.Ct[(size_t)(lane < C.MJ ? lane : 0) * C.N + j];  // (requested with the column: one round trip)
+    axpy_dense(hq, C.V + (size_t)j * C.N, dz, C.N);
     bEv = (lane < C.MJ) ? fma(-cj, dz, bEv) : bEv;
 }
 
@@ -1472,21 +1472,25 @@ __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int 
         prod[w] = s;
     }
     wave_sum_multi<NR>(prod, sums);
+    {   // lane w takes its own sum: the new border row goes to LDS (and t_w = H[w][c] follows the change of c) in ONE
+        // parallel step instead of a chain of read-modify-writes by lane 0
+        double sl = 0.0;
+#pragma unroll
+        for (int w = 0; w < NR; ++w) sl = (lane == w) ? sums[w] : sl;
+        const bool live = lane < MJ || lane == CC;
+        const double yl = ((lane == CC) ? hj : cj) - sl;
+        if (dz != 0.0 && lane < MJ) {
+            const double hv = fma(dz, sl, L.H[lane * NR + CC]);
+            L.H[lane * NR + CC] = hv;
+            L.H[CC * NR + lane] = hv;
+        }
+        if (lane < NR) L.yn[lane] = live ? yl : 0.0;
+    }
 #pragma unroll
     for (int w = 0; w < NR; ++w) {
         if (w < MJ || w == CC) {  // uniform
             const double xw = (w == CC) ? hj : readlane_f64(cj, w < MJX ? w : 0);
-            const double s = sums[w];
-            const double yk = xw - s;
-            if (dz != 0.0 && w < MJX && lane == 0) {  // t_w = H[w][c] follows the change of c
-                const double hv = fma(dz, s, L.H[w * NR + CC]);
-                L.H[w * NR + CC] = hv;
-                L.H[CC * NR + w] = hv;
-            }
-            set_row<SL>(R.Y[w], K, yk);
-            if (lane == 0) L.yn[w] = yk;
-        } else if (lane == 0) {
-            L.yn[w] = 0.0;
+            set_row<SL>(R.Y[w], K, xw - sums[w]);
         }
     }
     if (lane < 16) L.xn[lane] = (lane < MJ) ? cj : 0.0;
