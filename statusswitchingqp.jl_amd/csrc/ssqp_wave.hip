@@ -662,8 +662,12 @@ __device__ __forceinline__ double append_row(const WLds &L, Rows &R, int K, int 
 // Delete row p: L33 D3 L33' += d_p l l' on the trailing block (rank-1 update, one column per step), then the
 // row/column is removed from the packed storage.  pv receives p_k = (L33^-1 l)_k in row k (the downdate of H
 // and nothing else needs it); dg/rd of the rows > p are updated in place (still in their OLD positions).
-template <int SL>
+// MERGE (one row slot, the whole factor in LDS): the updated column k is written straight to where the compaction would
+// move it -- column k - 1, rows r - 1; that storage (the old column k - 1) was consumed an iteration ago -- and
+// delete_compact only has the columns left of p to do.
+template <int SL, bool MERGE = false>
 __device__ __forceinline__ void delete_update(const Fac &F, Rows &R, int K, int p, double (&pv)[NSL], double (&bt)[NSL]) {
+    static_assert(!MERGE || SL == 1, "the merged form is for the one-slot factor");
     const int lane = lane_id();
     double w[NSL];
     load_col<SL>(F, K, p, w);
@@ -691,14 +695,18 @@ __device__ __forceinline__ void delete_update(const Fac &F, Rows &R, int K, int 
             }
             const bool below = r > k && r < K;
             w[t] = below ? fma(-pk, lc[t], w[t]) : w[t];
-            fac_put<SL>(F, r, k, fma(beta, w[t], lc[t]), below);
+            if (MERGE) {
+                if (below) F.L0[cofs64(k - 1) - (k - 1) + (r - 1)] = fma(beta, w[t], lc[t]);
+            } else {
+                fac_put<SL>(F, r, k, fma(beta, w[t], lc[t]), below);
+            }
         }
 #pragma unroll
         for (int t = 0; t < SL; ++t) lc[t] = ln[t];
     }
     wave_sync();
 }
-template <int SL>
+template <int SL, bool MERGE = false>
 __device__ __forceinline__ void delete_compact(const Fac &F, int K, int p) {
     const int lane = lane_id();
     constexpr int CB = 4;  // columns per read / write round (their storage is disjoint)
@@ -726,8 +734,8 @@ __device__ __forceinline__ void delete_compact(const Fac &F, int K, int p) {
         }
     }
     // column c -> c - 1, rows r > c -> r - 1, ascending: the target of column c is the storage of column c - 1, which
-    // this round (or an earlier one) has already read
-    for (int c0 = p + 1; c0 < K; c0 += CB) {
+    // this round (or an earlier one) has already read  (MERGE: delete_update has written them in place)
+    for (int c0 = p + 1; c0 < K && !MERGE; c0 += CB) {
         double a[CB][NSL];
 #pragma unroll
         for (int u = 0; u < CB; ++u) {
@@ -1575,11 +1583,12 @@ __device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p
         dgold[t] = R.dg[t];
     }
     constexpr bool STREAM = NSL > 2 && SL >= 2;  // (big-factor build: update and compaction in one streamed pass)
+    constexpr bool MERGE = !STREAM && SL == 1;   // (one row slot: the update writes the compacted positions itself)
     if (STREAM) {
         if (K <= 192) delete_stream<SL, 1>(L, R, K, p, pv, bt);
         else delete_stream<SL, 2>(L, R, K, p, pv, bt);
     } else {
-        delete_update<SL>(L.F, R, K, p, pv, bt);
+        delete_update<SL, MERGE>(L.F, R, K, p, pv, bt);
     }
     if (downdate) {
         // H' = H - g g' / m,  g = [A;G c']' V_FF^-1 e_p = Y' D^-1 f,  m = (V_FF^-1)_pp = f' D^-1 f,
@@ -1622,7 +1631,7 @@ __device__ __forceinline__ void delete_var(const WLds &L, Rows &R, int &K, int p
         gg_rank1(L, -1.0);
         wave_sync();
     }
-    if (!STREAM) delete_compact<SL>(L.F, K, p);
+    if (!STREAM) delete_compact<SL, MERGE>(L.F, K, p);
     // per-row registers: rows above p move up
     const int rp = rbcast_i<SL>(R.rank, p);
     shift_up_i<SL>(R.ord, p);
