@@ -710,6 +710,28 @@ template <int SL, bool MERGE = false>
 __device__ __forceinline__ void delete_compact(const Fac &F, int K, int p) {
     const int lane = lane_id();
     constexpr int CB = 4;  // columns per read / write round (their storage is disjoint)
+    if (MERGE && SSQP_WAVE_VARIANT != 1) {  // (not in the eight-per-CU build: it costs that build nine more spilled registers and 3 %)
+        // one row slot, packed columns in LDS: rows r > p of a column c < p move up by one INSIDE the column -- lane r reads
+        // its lower neighbour's entry and stores it as its own; eight columns per round, reads before stores (a
+        // wavefront's LDS operations execute in order)
+        const bool mv = lane >= p && lane + 1 < K;
+        const int src = lane + 1 < 64 ? lane + 1 : 63;
+        for (int c0 = 0; c0 < p; c0 += 8) {
+            double a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = (c0 + u < p) ? c0 + u : c0;
+                a[u] = F.L0[cofs64(c) - c + src];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u;
+                if (c < p && mv) F.L0[cofs64(c) - c + lane] = a[u];
+            }
+        }
+        wave_sync();
+        return;
+    }
     for (int c0 = 0; c0 < p; c0 += CB) {  // columns c < p lose row p: rows r > p move up by one inside the column
         double a[CB][NSL];
 #pragma unroll
