@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # vector-instruction issue: 256 CUs x 4 SIMDs at 2.4 GHz, one wave64 f64 VALU instruction per 4 cycles per SIMD (16 f64
 # lanes per cycle = the 78.6 TFLOP/s vector-f64 figure; the SQ counters agree: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.05
 # quad-cycles per instruction for this kernel)
-VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0
+VALU_ISSUE_PER_CU = 4 * 2.4e9 / 4.0   # x the device's CU count (256 on MI355X), read from the device at run time
 KERNEL_SOURCES = ["ssqp_wave.hip", "ssqp_kernels.hip", "ssqp_device.h", "ssqp_internal.h", "ssqp_api.hip",
                   "ssqp_phase1.hip", "ssqp_host.cpp", "../../include/ssqp_hip.h"]
 
@@ -64,6 +64,9 @@ def parse_args():
     ap.add_argument("--skip-dense", action="store_true",
                     help="do not time the dense-formulation launches (profiling runs want one kernel variant)")
     ap.add_argument("--dense", action="store_true", help="time the dense (reference-shaped) formulation as the main run")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of --steps steps: the first is the contractual one (`value`), the others give "
+                         "the median (SURVEY.md 8d: median of >= 5 repetitions)")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_counters.json"),
                     help="per-launch PMC figures (HBM bytes, SQ counters) from separate rocprofv3 --pmc passes")
     return ap.parse_args()
@@ -120,6 +123,8 @@ def run(args):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    num_cu = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+    valu_issue_peak = num_cu * VALU_ISSUE_PER_CU
     cfg = pkg.CONFIGS[args.config]
     ncpu = usable_cores()
     gen_threads = max(1, ncpu // max(1, min(world, 8)))
@@ -250,7 +255,7 @@ def run(args):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         mode = "lanes" if int(flag.item()) == 1 else "serial"
     set_mode(mode)
-    qpc_timed = 8 if mode == "lanes" else (8 if P > 4 * 256 else 4)
+    qpc_timed = 8 if mode == "lanes" else (8 if P > 4 * num_cu else 4)
 
     # ---- the timed region
     timed(0)                                                 # (settle: the counters below cover the timed steps only)
@@ -258,6 +263,7 @@ def run(args):
     events = []
     elapsed = timed(args.steps, events)
     alloc1 = n_allocs()
+    gathers_timed = state["gathers"]
     assert world == 1 or state["gathers"] == args.steps, (state["gathers"], args.steps)   # one gather per timed step, all inside
     launch_ms = [e0.elapsed_time(e1) for e0, e1 in events]   # whole solve() calls: S reset, counters, prep kernel, solve kernels
     # the solve kernels alone: HIP events the library records around them on the stream of each launch (it keeps the
@@ -274,6 +280,16 @@ def run(args):
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if not rehearsal else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # further repetitions of the same region (same steps, same fences): `value` stays the first, contractual region;
+    # the median over all of them is reported beside it
+    rep_s = [elapsed]
+    for _ in range(max(0, args.repeats - 1)):
+        e = timed(args.steps)
+        if world > 1:
+            tt = torch.tensor([e], dtype=torch.float64, device=dev if not rehearsal else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            e = float(tt.item())
+        rep_s.append(e)
 
     used = lanes[:min(nlanes, args.steps)]
     results = [ln.batch.results() for ln in lanes]
@@ -396,14 +412,14 @@ def run(args):
     def issue_block(sqc, ms, iters_sum, what):
         if not sqc or "SQ_INSTS_VALU" not in sqc:
             return None
-        return {"bound": "valu-issue", "achieved": sqc["SQ_INSTS_VALU"] / (ms * 1e-3), "peak": VALU_ISSUE_PEAK,
-                "unit": "wave-instructions/s", "frac": sqc["SQ_INSTS_VALU"] / (ms * 1e-3) / VALU_ISSUE_PEAK,
+        return {"bound": "valu-issue", "achieved": sqc["SQ_INSTS_VALU"] / (ms * 1e-3), "peak": valu_issue_peak,
+                "unit": "wave-instructions/s", "frac": sqc["SQ_INSTS_VALU"] / (ms * 1e-3) / valu_issue_peak,
                 "issue_active_frac": sqc["SQ_ACTIVE_INST_ANY"] / sqc["SQ_WAVE_CYCLES"],
                 "wait_frac": sqc["SQ_WAIT_ANY"] / sqc["SQ_WAVE_CYCLES"],
                 "valu_per_pass": sqc["SQ_INSTS_VALU"] / iters_sum, "salu_per_pass": sqc["SQ_INSTS_SALU"] / iters_sum,
                 "note": "SQ counters per launch of " + what + " from profiles/ (same source hash, separate --pmc passes) / "
-                        "the time one launch's worth of work takes here; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles "
-                        "per wave64 f64 VALU instruction"}
+                        "the time one launch's worth of work takes here; peak = %d CUs x 4 SIMDs x 2.4 GHz / 4 cycles "
+                        "per wave64 f64 VALU instruction" % num_cu}
 
     out = None
     if rank == 0:
@@ -419,9 +435,11 @@ def run(args):
             kname = "ssqp_solve_kernel"
         conc = max(1.0, in_flight)
         achieved = read_bytes * conc / (k_ms * 1e-3) / 1e9
-        hot_set = qpc_timed * 256 * mean_maxk * N * 8.0
+        hot_set = qpc_timed * num_cu * mean_maxk * N * 8.0
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "achieved_is": "ALGORITHMIC bytes per second: what the formulation reads, counted in-kernel, L2 and "
+                               "Infinity-Cache hits included -- an upper bound on the DRAM share, not a DRAM rate",
                 "kernel": kname, "mode": mode, "wave_qp_per_cu": qpc_timed,
                 "kernel_ms": k_ms, "launches_in_flight": in_flight, "alg_bytes_per_launch": read_bytes,
                 "achieved_from_traffic": None if traffic is None else traffic * conc / (k_ms * 1e-3) / 1e9,
@@ -439,7 +457,8 @@ def run(args):
                         "hot_set_in_flight_bytes (QPs in flight x mean final free set x one column) of the order of the "
                         "256 MiB Infinity Cache, frac_from_traffic is an upper bound on the DRAM share.  About 6.3 TB/s "
                         "are achievable.  Serial single launches: roofline_serial; the reference-shaped formulation: "
-                        "roofline_dense_formulation"}
+                        "roofline_dense_formulation.  With lazy_handover a launch that owed a later stage has its end event "
+                        "re-recorded behind that stage, host gap included (cfg4 owes none; cfg3 is timed with serial launches)"}
         issue = issue_block(sq, k_ms / conc, float(iters.sum()) / len(used), "the timed build")
         roof_serial = {"bound": "hbm", "achieved": read_serial / (iso_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": read_serial / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_serial,
@@ -452,11 +471,16 @@ def run(args):
             "metric": "QPs/sec (batched N=512 dense portfolio QP, solveQP(Q,S,x0) to KKT)",
             "value": qps, "unit": "QPs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "repeats": {"ms_per_step": [1e3 * e / args.steps for e in rep_s],
+                        "ms_per_step_median": 1e3 * float(np.median(rep_s)) / args.steps,
+                        "value_median": world * P * args.steps / float(np.median(rep_s)),
+                        "note": "the same timed region repeated; `value` / `ms_per_step` are the first one"},
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d QPs/GPU per step, N=%d M=%d J=%d, V=X'X/T+%g*I, box [0,%g], Phase-1 vertex "
                                    "resident in HBM; %d distinct batches per GPU (seeds %d + lane*%d), one per launch lane"
                                    % (args.config, P, N, batch.M, J, cfg.delta, cfg.ub, nlanes, lanes[0].seed0, P),
                        "qps_per_gpu": P,
+                       "compute_units": num_cu,
                        "parallelism": "one QP per wavefront (%d per CU in the timed region), batch sharded over %d GPU(s)"
                                       % (qpc_timed, world),
                        "formulation": "dense (reference-shaped)" if args.dense else "default (kept factor, cached products)"},
@@ -474,7 +498,7 @@ def run(args):
                                  "launch overlaps the ramp-up of the next; mode serial = the same batches one after the "
                                  "other on one stream.  Both modes are probed after warm-up and the faster one is timed; "
                                  "every step solves all its QPs from (x0, S0)"},
-            "collective": {"gathers": state["gathers"], "per_step": 1 if world > 1 else 0,
+            "collective": {"gathers": gathers_timed, "per_step": 1 if world > 1 else 0,
                            "bytes_per_rank_per_step": (lanes[0].pg.bytes if world > 1 else 0),
                            "cuda_allocations_in_timed_region": int(alloc1 - alloc0),
                            "of_which_inside_the_backend_collective_call": int(state["coll_allocs"]),

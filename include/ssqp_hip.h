@@ -168,7 +168,8 @@ int ssqp_solve_full_f64(ssqp_ctx *ctx, int N, int M, int J, const double *V, con
  *   gamma[i]   gamma (SSQP.jl:352) of bound variable i (sign as in the reference: an UP variable is optimal when
  *              gamma <= tolG, a DN variable when gamma >= -tolG); 0 for free variables
  * On the K == 0 exit (SSQP.jl:278-285; no multipliers exist there) gamma = V z + q, lambda = 0.  Not written for
- * status <= 0.  The reference keeps these inside solveQP; they are exported so that north_star's "x/lambda within
+ * status <= 0: every entry point (host buffers and device buffers alike) ZEROES the arrays it is given before the launch
+ * -- on `stream` for the device entries -- so a QP that does not converge reads 0, never an earlier call's values.  The reference keeps these inside solveQP; they are exported so that north_star's "x/lambda within
  * 1e-10" can be checked at the boundary. */
 int ssqp_solve_batch_f64(ssqp_ctx *ctx, int nprob, int N, int M, int J, const double *V,
                          const double *A, const double *G, const double *q, const double *b,
@@ -229,6 +230,10 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *ctx, int nprob, int N, int M, int
  * not for the stream).  A host that reuses the call's in/out buffers (S is in/out) must flush BEFORE it queues work
  * that overwrites them. */
 int ssqp_flush(ssqp_ctx *ctx);
+/* ssqp_flush, after which `stream` also waits for the owed launch when that went out on ANOTHER stream: what a host
+ * calls before it queues, on `stream`, work that overwrites the in/out buffers of the previous call on ctx (a copy
+ * that resets S, say) -- ssqp_flush alone orders such work only on the stream of the previous call. */
+int ssqp_flush_to(ssqp_ctx *ctx, void *stream);
 /* waits for `stream`; with "lazy_handover" it first issues the launch the last call on ctx may still owe */
 int ssqp_sync(ssqp_ctx *ctx, void *stream);
 /* duration in ms of the solve kernel(s) of the most recent ssqp_solve_batch_dev_f64

@@ -11,8 +11,10 @@ from ._capi import LIB_PATH, NoDeviceError, SSQPError
 from .solver import (BASE_SEED, CONFIGS, Context, DeviceBatch, GenConfig, ResidentBatch, default_context, generate_batch,
                      phase1_batch, solveQP, solveQP_batch, solveQP_batch_multi)
 from .types import DN, EO, IN, OE, UP, QP, DimensionMismatch, Settings, Status
-from .optimizer import Optimizer, ResultStatus, TerminationStatus
+from .optimizer import (Optimizer, ResultStatus, TerminationStatus, UnsupportedConstraint, UnsupportedModel, get_constraints,
+                        moi_to_qp)
 
 __all__ = ["Status", "IN", "DN", "UP", "OE", "EO", "Settings", "QP", "solveQP", "solveQP_batch", "solveQP_batch_multi", "Context",
            "DeviceBatch", "ResidentBatch", "GenConfig", "CONFIGS", "BASE_SEED", "generate_batch", "phase1_batch", "NoDeviceError",
-           "SSQPError", "DimensionMismatch", "LIB_PATH", "default_context", "Optimizer", "TerminationStatus", "ResultStatus"]
+           "SSQPError", "DimensionMismatch", "LIB_PATH", "default_context", "Optimizer", "TerminationStatus", "ResultStatus",
+           "moi_to_qp", "get_constraints", "UnsupportedConstraint", "UnsupportedModel"]

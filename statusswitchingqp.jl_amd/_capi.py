@@ -76,6 +76,7 @@ SIGNATURES = {
                                          [_vp, _vp, _vp, C.POINTER(CSettings), _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "ssqp_sync": (C.c_int, [_vp, _vp]),
     "ssqp_flush": (C.c_int, [_vp]),
+    "ssqp_flush_to": (C.c_int, [_vp, _vp]),
     "ssqp_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "ssqp_recent_kernel_ms": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float)]),
     "ssqp_phase1_f64": (C.c_int, [C.c_int] * 3 + [_vp] * 6 + [C.POINTER(CSettings), _vp, _vp, _ip]),

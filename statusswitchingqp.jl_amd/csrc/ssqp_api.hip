@@ -246,6 +246,13 @@ int ssqp_flush(ssqp_ctx *c) {
     return finish_pending(c);
 }
 
+int ssqp_flush_to(ssqp_ctx *c, void *stream) {
+    if (!c) return SSQP_ERR_ARG;
+    if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return SSQP_ERR_HIP;
+    const int rc = finish_pending(c);
+    return rc != SSQP_OK ? rc : order_after_owed(c, (hipStream_t)stream);
+}
+
 int ssqp_sync(ssqp_ctx *c, void *stream) {
     if (!c) return SSQP_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;  // NULL is HIP's default stream, as everywhere in HIP
@@ -302,6 +309,9 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
     }
 
     const int MJ = M + J;
+    // the multipliers are written for status > 0 only: every call starts them from zero (include/ssqp_hip.h)
+    if (dlambda && MJ > 0 && !hip_ok(c, hipMemsetAsync(dlambda, 0, (size_t)nprob * MJ * 8, s), "hipMemsetAsync")) return SSQP_ERR_HIP;
+    if (dgamma && !hip_ok(c, hipMemsetAsync(dgamma, 0, (size_t)nprob * N * 8, s), "hipMemsetAsync")) return SSQP_ERR_HIP;
     // workgroups per CU: LDS is the limit.  3 when the N-vectors leave a useful arena in 1/3 of the 160 KiB,
     // else 2, else 1 (SSQP_WG_PER_CU overrides for experiments).  A pass whose factor does not fit the LDS
     // arena runs on the per-workgroup global arena instead, so any choice is correct.
@@ -531,9 +541,7 @@ int ssqp_solve_batch_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const doub
         !ensure(c, c->hstats, P * sizeof(ssqp_stats)))
         return SSQP_ERR_ALLOC;
     if ((lambda && !ensure(c, c->hlam, P * (m + j) * 8)) || (gamma && !ensure(c, c->hgam, P * n * 8))) return SSQP_ERR_ALLOC;
-    // (multipliers are written for status > 0 only: the buffers start from zero)
-    if (lambda && (m + j) > 0 && !hip_ok(c, hipMemsetAsync(c->hlam.p, 0, P * (m + j) * 8, c->stream), "hipMemsetAsync")) return SSQP_ERR_HIP;
-    if (gamma && !hip_ok(c, hipMemsetAsync(c->hgam.p, 0, P * n * 8, c->stream), "hipMemsetAsync")) return SSQP_ERR_HIP;
+    // (multipliers are written for status > 0 only: the device entry every chunk goes through zeroes its part first)
     // The upload of V (N*N*8 bytes per QP over PCIe) dwarfs the solve: the batch goes up in chunks, and every chunk is
     // solved on one of four launch lanes (child contexts) as soon as it has landed -- the solves run behind the
     // upload of the following chunks and beside each other, so the call takes the transfer plus one chunk's solve.

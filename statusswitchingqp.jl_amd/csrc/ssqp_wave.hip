@@ -70,8 +70,11 @@ constexpr int NSL = 2;
 #endif
 // only the big-factor build is ever launched on a hand-over list (P.resume): the other builds do not carry the code
 constexpr bool CAN_RESUME = NSL > 2;
-[[maybe_unused]] constexpr int WAVE_LS_DOUBLES = 128 * MJX + MJX * MJX + MJX + 21;  // global scratch of the purged-row least squares
-[[maybe_unused]] constexpr int WAVE_LS_DOUBLES_BIG = 256 * MJX + MJX * MJX + MJX + 21;  // ... of the big-factor build (up to 256 rows)
+// (rounded up to whole 128-byte lines: the factor storage behind it, and with it every 1 KiB DMA piece and every double2
+//  access, then starts on a cache-line boundary in every wavefront's scratch -- the per-wavefront stride is a multiple too)
+[[maybe_unused]] constexpr int WAVE_LS_DOUBLES = (128 * MJX + MJX * MJX + MJX + 21 + 15) / 16 * 16;  // global scratch of the purged-row least squares
+[[maybe_unused]] constexpr int WAVE_LS_DOUBLES_BIG = (256 * MJX + MJX * MJX + MJX + 21 + 15) / 16 * 16;  // ... of the big-factor build (up to 256 rows)
+static_assert(WAVE_LS_DOUBLES % 16 == 0 && WAVE_LS_DOUBLES_BIG % 16 == 0, "line-aligned factor storage");
 constexpr double INF = __builtin_huge_val();
 
 // compile-time loop: the body sees its index as a constant, so every register-array index is static whatever
@@ -360,8 +363,9 @@ constexpr int RING_BYTES = 16 * 1024;
 
 // One LDS-DMA load, 16 B per lane: global address = the UNIFORM 64-bit base `sbase` + this lane's byte offset `voff`;
 // LDS destination = M0 base `lds_dst` + lane * 16.  The base travels in a scalar register pair and the per-lane offsets
-// of a stream are loop-invariant, so a piece costs s_mov m0 + s_nop + the load.  M0 is NOT saved: nothing else in these
-// kernels uses it (no ds_gws, no s_movrel, no LDS-direct; tests/test_capi_cpu.py checks the built code object for that).
+// of a stream are loop-invariant, so a piece costs s_mov m0 + s_nop + the load.  M0 is NOT saved: the statement lists it
+// as clobbered, and nothing else in these kernels uses it (no ds_gws, no s_movrel, no LDS-direct; tests/test_capi_cpu.py
+// checks the built code objects for that).
 __device__ __forceinline__ const double *uni_ptr(const double *p) {  // a uniform pointer, pinned to a scalar register pair
     const unsigned long long a = (unsigned long long)p;
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
@@ -372,7 +376,7 @@ __device__ __forceinline__ void glds16_s(const void *sbase, unsigned voff, unsig
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0"
                  :
                  : "s"(sbase), "v"(voff), "s"(lds_dst)
-                 : "memory");
+                 : "memory", "m0");
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() {

@@ -1,10 +1,13 @@
 """Host-side mirror of the reference's plugin entry for the hot path -- StatusSwitchingQP.Optimizer
 (src/MOIwrapper.jl): the dispatch of MOI.optimize! (:131-171) and the result getters that depend on the
-solver's return triple (:189-251).  Only what touches solveQP is mirrored; building a QP from a MathOptInterface
-model (MOI2QP, :422-458) needs the MathOptInterface package and stays Julia (julia/SSQPHip.jl).
+solver's return triple (:189-251), and the INGEST half -- MOI.copy_to (:120-128), MOI2QP (:422-458) and
+getConstraints (:262-349) -- on neutral input: the model arrives as plain term lists (what a
+MOI.ScalarQuadraticFunction and the constraint list hold), not as a MathOptInterface object; the
+MathOptInterface plumbing itself stays Julia (julia/SSQPHip.jl).
 
     opt = Optimizer(maxIter=500)          # kwargs go to Settings, unknown ones are rejected (:17-31)
     opt.copy_to(Q)                        # Q: a QP (what MOI.copy_to leaves in opt.Problem, :120-128)
+    opt.copy_to_terms(N, quadratic_terms, affine_terms, constant, sense, constraints)   # ... or the model as terms
     opt.optimize()                        # MOI.optimize!
     opt.termination_status(), opt.primal_status(), opt.objective_value(), opt.variable_primal()
 """
@@ -81,6 +84,22 @@ class Optimizer:
         self.Problem = problem
         self.Results = None
 
+    def copy_to_terms(self, N, quadratic_terms, affine_terms, constant=0.0, sense=MIN_SENSE, constraints=()):
+        """MOI.copy_to(dest, src) (:120-128) for a model given as term lists (see moi_to_qp): sense first (:121), then
+        MOI2QP (:122); a model whose V is all zero is an LP (:123-126) -- the reference rebuilds it as LP(...) for
+        SimplexLP, which is outside this repository's scope, so it is REFUSED here."""
+        self.Sense = sense
+        Q, f0 = moi_to_qp(N, quadratic_terms, affine_terms, constant, sense, constraints)
+        self.f0 = f0                                        # :445
+        if np.abs(Q.V).max(initial=0.0) == 0:               # norm(V, Inf) == 0  (:123; entrywise for a Matrix)
+            self.Problem = None
+            self.Results = None
+            raise UnsupportedModel("LP model (V == 0): the reference hands it to SimplexLP (MOIwrapper.jl:123-126,167), "
+                                   "which is out of scope here")
+        self.Problem = Q
+        self.Results = None
+        return Q
+
     # -- MOI.optimize! (:131-171)
     def optimize(self):
         P = self.Problem
@@ -139,6 +158,94 @@ class Optimizer:
     def variable_primal(self, index=None):
         x = self.Results[0]
         return x if index is None else x[index]    # :243-250 (0-based here)
+
+
+class UnsupportedConstraint(ValueError):
+    """MOI.UnsupportedConstraint{F,S} (:298,317,320)"""
+
+
+class UnsupportedModel(ValueError):
+    pass
+
+
+EQUAL_TO, GREATER_THAN, LESS_THAN, INTERVAL = "EqualTo", "GreaterThan", "LessThan", "Interval"
+
+
+def get_constraints(N, constraints):
+    """getConstraints(P, N, T) (MOIwrapper.jl:262-349) on a neutral constraint list.  Each constraint is
+        ("affine", [(i, coef), ...], set, value)       a MOI.ScalarAffineFunction row, variables 0-based
+        ("variable", i, set, value)                    a MOI.VariableIndex bound
+    with set in {EqualTo, GreaterThan, LessThan, Interval} and value a number (a (lower, upper) pair for Interval).
+    As in the reference: a row's coefficients are ASSIGNED per term (a repeated variable keeps its LAST coefficient,
+    :274-276 -- not summed, unlike the objective), a row without terms is skipped with a warning (:278-282),
+    `>=` rows are negated into `<=` rows (:286-288), Interval is accepted for variables only, EqualTo for rows only;
+    variables start unbounded, d = -Inf, u = +Inf (:266-267).  Returns A, b, G, g, d, u."""
+    import warnings
+    Ab, Gg = [], []
+    d = np.full(N, -np.inf)
+    u = np.full(N, np.inf)
+    for con in constraints:
+        kind, f, S, val = con
+        if kind == "affine":
+            t = np.zeros(N + 1)
+            nt = 0
+            for i, coef in f:
+                t[i] = coef
+                nt += 1
+            if nt == 0:
+                warnings.warn("skipping redundant rows")
+                continue
+            if S == EQUAL_TO:
+                t[-1] = val
+                Ab.append(t)
+            elif S == GREATER_THAN:
+                t[-1] = val
+                Gg.append(-t)
+            elif S == LESS_THAN:
+                t[-1] = val
+                Gg.append(t)
+            else:
+                raise UnsupportedConstraint("ScalarAffineFunction-in-" + str(S))
+        elif kind == "variable":
+            if S == GREATER_THAN:
+                d[f] = val
+            elif S == LESS_THAN:
+                u[f] = val
+            elif S == INTERVAL:
+                d[f], u[f] = val
+            else:
+                raise UnsupportedConstraint("VariableIndex-in-" + str(S))
+        else:
+            raise UnsupportedConstraint(str(kind))
+    M, J = len(Ab), len(Gg)
+    A = np.array([t[:-1] for t in Ab]).reshape(M, N)
+    b = np.array([t[-1] for t in Ab]).reshape(M)
+    G = np.array([t[:-1] for t in Gg]).reshape(J, N)
+    g = np.array([t[-1] for t in Gg]).reshape(J)
+    return A, b, G, g, d, u
+
+
+def moi_to_qp(N, quadratic_terms, affine_terms, constant=0.0, sense=MIN_SENSE, constraints=()):
+    """MOI2QP (MOIwrapper.jl:422-458) on neutral input: the objective f = (1/2) z'Vz + q'z + f0 as the term lists of a
+    MOI.ScalarQuadraticFunction -- quadratic_terms [(i, j, coef), ...], affine_terms [(i, coef), ...], 0-based.
+    As in the reference: duplicate terms are SUMMED (:431-433, :442-444); then every off-diagonal pair is folded,
+    V[i,j] += V[j,i] for i > j, and mirrored (:434-439) -- MathOptInterface lists an off-diagonal term once, standing for
+    both V[i,j] and V[j,i]; MAX_SENSE negates V and q (:447-450); the constant goes to f0 (:445).  Returns (QP, f0)."""
+    V = np.zeros((N, N))
+    for i, j, coef in quadratic_terms:
+        V[i, j] += coef
+    for i in range(1, N):
+        for j in range(i):
+            V[i, j] += V[j, i]
+            V[j, i] = V[i, j]
+    q = np.zeros(N)
+    for i, coef in affine_terms:
+        q[i] += coef
+    if sense == MAX_SENSE:
+        V = -V
+        q = -q
+    A, b, G, g, d, u = get_constraints(N, constraints)
+    return QP(V, A=A, G=G, q=q, b=b, g=g, d=d, u=u), float(constant)
 
 
 def _backslash(A, b):

@@ -95,6 +95,10 @@ class Context:
         """lazy_handover: issue what the last call still owes before its in/out buffers are reused"""
         _capi.check(_capi.lib().ssqp_flush(self._h), self._h)
 
+    def flush_to(self, stream):
+        """flush(), and `stream` (a raw hipStream_t) then waits for the owed launch if that went out on another stream"""
+        _capi.check(_capi.lib().ssqp_flush_to(self._h, C.c_void_p(stream)), self._h)
+
     def sync(self, stream=None):
         _capi.check(_capi.lib().ssqp_sync(self._h, stream), self._h)
 
@@ -394,7 +398,6 @@ class DeviceBatch:
         Arrays given with a leading dimension of 1 are shared by every problem of the batch (stride 0)."""
         torch = self.torch
         cs = _csettings(settings)
-        self.ctx.flush()   # (lazy hand-over: the previous launch on this context is complete before S is reset)
         # S is in/out: the reset runs on the SAME stream as the launch (a raw hipStream_t is wrapped, so the copy
         # cannot race with the kernels of this or the previous launch on that stream)
         if stream is None:
@@ -403,6 +406,9 @@ class DeviceBatch:
             tstream = torch.cuda.ExternalStream(stream, device=self.S.device)
         else:
             tstream = stream
+        # lazy hand-over: what the previous call on this context still owes goes out first, and this call's stream waits
+        # for it even when that call ran on ANOTHER stream (the owed stages read and write S and z)
+        self.ctx.flush_to(tstream.cuda_stream)
         with torch.cuda.stream(tstream):
             self.S.copy_(self.S0)
         stream = tstream.cuda_stream

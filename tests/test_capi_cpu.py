@@ -106,38 +106,99 @@ def test_qp_constructor_mirrors_reference(pkg):
     assert [int(s) for s in (pkg.IN, pkg.DN, pkg.UP, pkg.OE, pkg.EO)] == [0, 1, 2, 3, 4]        # types.jl:17-23
 
 
-def test_m0_belongs_to_the_lds_dma_loads():
-    """The LDS-DMA loads of the big-factor build (glds16_s in ssqp_wave.hip) set M0 and do not restore it: nothing else in
-    the library's kernels may use M0.  Checked on the code objects of the built device objects."""
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _device_disassemblies():
+    """(object path, [(address, instruction text, branch target address or None)]) of every built device object of the library"""
     import glob
     import shutil
     import subprocess
     import tempfile
-    llvm = "/opt/rocm/lib/llvm/bin"
     objs = [o for o in sorted(glob.glob(os.path.join(ROOT, "statusswitchingqp.jl_amd", "csrc", "ssqp_*.o")))
-            if "_prof" not in o and not o.endswith("ssqp_host.o")]
-    if not (objs and os.path.exists(os.path.join(llvm, "llvm-objdump"))):
-        pytest.skip("no built objects / no llvm tools")
-    n_dma = n_load = 0
+            if "_prof" not in o and "_diag" not in o and not o.endswith("ssqp_host.o")]
+    built = os.path.exists(os.path.join(ROOT, "statusswitchingqp.jl_amd", "libssqp_hip.so"))
+    if not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        pytest.skip("no llvm tools in this image")
+    # (a box that has the library but not its objects -- the GPU box gets both -- cannot run this; the build box must)
+    assert objs or not built, "libssqp_hip.so is built but its device objects are gone: run `make` in csrc/"
+    if not objs:
+        pytest.skip("library not built")
+    out = []
     tmp = tempfile.mkdtemp()
     try:
         for o in objs:
             fb, co = os.path.join(tmp, "fb.bin"), os.path.join(tmp, "dev.co")
-            subprocess.run([f"{llvm}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", o, fb], check=True)
-            un = subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fb}",
+            subprocess.run([f"{LLVM}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", o, fb], check=True)
+            un = subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fb}",
                                  "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], capture_output=True)
             if un.returncode != 0:
                 continue  # (an object without device code)
-            dis = subprocess.run([f"{llvm}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
-            ins = [ln.split("//")[0].strip() for ln in dis.splitlines() if "//" in ln]
-            for i, s in enumerate(ins):
-                if s.startswith("global_load_lds_dwordx4"):
-                    n_load += 1
-                if not re.search(r"\bm0\b", s):
+            dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+            ins = []
+            for ln in dis.splitlines():
+                m = re.match(r"\s+(\S.*?)\s*// ([0-9A-F]{12}):", ln)
+                if not m:
                     continue
-                assert re.fullmatch(r"s_mov_b32 m0, s\d+", s), (o, s)
-                assert ins[i + 1].startswith("s_nop") and ins[i + 2].startswith("global_load_lds_dwordx4"), (o, ins[i:i + 3])
-                n_dma += 1
+                a, text, tgt = int(m.group(2), 16), m.group(1).strip(), None
+                b = re.match(r"s_c?branch\w*\s+(\d+)$", text)
+                if b:  # SOPP branch: simm16 dwords relative to the next instruction
+                    off = int(b.group(1))
+                    tgt = a + 4 + 4 * (off - 65536 if off >= 32768 else off)
+                ins.append((a, text, tgt))
+            out.append((o, ins))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def test_m0_belongs_to_the_lds_dma_loads():
+    """The LDS-DMA loads of the big-factor build (glds16_s in ssqp_wave.hip) set M0 and do not restore it (the asm
+    statement lists m0 as clobbered): nothing else in the library's kernels may use M0.  Checked on the code objects of
+    the built device objects."""
+    n_dma = n_load = 0
+    for o, ins3 in _device_disassemblies():
+        ins = [s for _, s, _ in ins3]
+        for i, s in enumerate(ins):
+            if s.startswith("global_load_lds_dwordx4"):
+                n_load += 1
+            if not re.search(r"\bm0\b", s):
+                continue
+            assert re.fullmatch(r"s_mov_b32 m0, s\d+", s), (o, s)
+            assert ins[i + 1].startswith("s_nop") and ins[i + 2].startswith("global_load_lds_dwordx4"), (o, ins[i:i + 3])
+            n_dma += 1
     assert n_dma == n_load > 0
+
+
+def test_no_store_inside_a_counted_wait_ring_loop():
+    """The LDS ring of the big-factor build is consumed behind COUNTED waits (`s_waitcnt vmcnt(N)`, N > 0: "all but the
+    N youngest vector-memory operations are done"), which is only a statement about the ring's LDS-DMA loads while
+    nothing else shares the counter inside the loop: loads return in order, but a STORE -- a register spill the
+    compiler placed there, say -- completes out of order with respect to them, and the wait could then pass with a ring
+    slot still in flight (ssqp_wave.hip, "the column ring").  So: no store instruction inside any innermost loop of a
+    wave build that holds an LDS-DMA load and a counted wait.  (The streamed delete stores on purpose and therefore
+    waits with vmcnt(0).)"""
+    store = re.compile(r"(scratch_store|global_store|buffer_store|flat_store|global_atomic|flat_atomic|buffer_atomic)")
+    n_loops = 0
+    for o, ins in _device_disassemblies():
+        if "ssqp_wave" not in os.path.basename(o):
+            continue
+        index = {a: i for i, (a, _, _) in enumerate(ins)}
+        loops = []
+        for i, (a, s, tgt) in enumerate(ins):
+            if re.match(r"s_c?branch", s) and tgt is not None and tgt <= a:
+                assert tgt in index, (o, s, hex(tgt))
+                loops.append((index[tgt], i))
+        starts = sorted(loops)
+        for b, e in loops:
+            if any(b2 >= b and e2 <= e and (b2, e2) != (b, e) for b2, e2 in starts):
+                continue  # not innermost
+            body = [s for _, s, _ in ins[b:e + 1]]
+            if not any(s.startswith("global_load_lds") for s in body):
+                continue
+            if not any(re.search(r"vmcnt\([1-9]\d*\)", s) for s in body):
+                continue
+            n_loops += 1
+            bad = [s for s in body if store.match(s)]
+            assert not bad, (o, hex(ins[b][0]), bad[:3])
+    assert n_loops > 100, n_loops  # (268 in the round-3 objects)

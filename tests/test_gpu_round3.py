@@ -165,19 +165,24 @@ def test_lazy_handover_host_buffer_entries(pkg, orc):
 
 
 def test_phase1_gpu_returns_on_poisoned_lp(pkg):
-    """a NaN in A: every comparison of the ratio test is false; the kernel must come back (status -1 or 0), not spin"""
+    """a NaN in A / G: every comparison that involves it is false, so the poisoned column never becomes a candidate
+    (its reduced cost is NaN) and never enters the xb sum (it sits at a zero bound): the host stage solves the LP around
+    it.  The GPU stage must come back -- not spin -- with exactly the host stage's status, x0 and S0."""
     import torch
     cfg = pkg.GenConfig(40, 1, 3, 80, 1e-3, 0.1, 1.0, 0.1)
     prob = pkg.generate_batch(cfg, 4, 5)
     prob["G"][1, 3, 0] = np.nan
     prob["A"][2, 5, 0] = np.nan
     P, N = prob["q"].shape
+    xh, Sh, sth = pkg.phase1_batch(prob)
     db = pkg.DeviceBatch(prob, np.zeros((P, N + cfg.J), dtype=np.int32), np.zeros((P, N)))
     st = db.phase1()
     torch.cuda.synchronize()
     st = st.cpu().numpy()
     assert st[0] == 1 and st[3] == 1           # the clean problems are untouched
-    assert set(st[1:3].tolist()) <= {-1, 0, 1}
+    assert np.array_equal(st, sth), (st, sth)
+    assert np.array_equal(db.S0.cpu().numpy(), Sh)
+    assert np.array_equal(db.x0.cpu().numpy(), xh, equal_nan=True)
 
 
 # ---------------------------------------------------------------- the big-factor build of the wavefront kernel

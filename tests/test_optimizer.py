@@ -45,6 +45,65 @@ def test_optimizer_presolve_and_status_table_cpu(pkg):
         assert o.primal_status() == pkg.ResultStatus.INFEASIBLE_POINT
 
 
+def test_moi_to_qp_mirrors_the_reference_ingest_cpu(pkg):
+    """MOI2QP (MOIwrapper.jl:422-458), getConstraints (:262-349) and copy_to's LP refusal (:123-126) on hand-built term
+    lists: duplicate objective terms summed, off-diagonals folded and mirrored, MAX_SENSE negation, f0; rows assigned
+    per term, `>=` rows negated, bounds from VariableIndex sets, defaults d = -Inf / u = +Inf"""
+    import warnings
+    # f = (1/2) z'Vz + q'z + 3 with V = [[2, 1.5, 0], [1.5, 4, -1], [0, -1, 6]]: the (0,1) pair given ONCE as 1.5 (MOI's
+    # convention), the (2,1) pair split over both orders, the diagonal (1,1) as two duplicate terms
+    quad = [(0, 0, 2.0), (0, 1, 1.5), (1, 1, 1.0), (1, 1, 3.0), (2, 1, -0.25), (1, 2, -0.75), (2, 2, 6.0)]
+    aff = [(0, 1.0), (2, -2.0), (0, 0.5)]
+    cons = [("affine", [(0, 1.0), (1, 1.0), (2, 1.0)], "EqualTo", 1.0),
+            ("affine", [(0, 1.0), (2, 2.0)], "GreaterThan", 0.25),
+            ("affine", [(1, 1.0), (1, 3.0)], "LessThan", 0.9),          # repeated variable: the LAST coefficient stays
+            ("affine", [], "LessThan", 5.0),                            # no terms: skipped with a warning
+            ("variable", 0, "GreaterThan", 0.0), ("variable", 1, "Interval", (0.1, 0.8)), ("variable", 2, "LessThan", 0.7)]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        Q, f0 = pkg.moi_to_qp(3, quad, aff, 3.0, "MIN_SENSE", cons)
+    assert any("redundant" in str(x.message) for x in w)
+    assert np.array_equal(Q.V, [[2, 1.5, 0], [1.5, 4, -1], [0, -1, 6]]) and Q.q.tolist() == [1.5, 0, -2] and f0 == 3.0
+    assert (Q.N, Q.M, Q.J, Q.mc) == (3, 1, 2, 1)
+    assert np.array_equal(Q.A, [[1, 1, 1]]) and Q.b.tolist() == [1.0]
+    assert np.array_equal(Q.G, [[-1, 0, -2], [0, 3, 0]]) and Q.g.tolist() == [-0.25, 0.9]
+    assert Q.d.tolist() == [0.0, 0.1, -np.inf] and Q.u.tolist() == [np.inf, 0.8, 0.7]
+    Qm, _ = pkg.moi_to_qp(3, quad, aff, 0.0, "MAX_SENSE", cons[:1] + cons[4:])
+    assert np.array_equal(Qm.V, -Q.V) and np.array_equal(Qm.q, -Q.q) and Qm.J == 0 and Qm.mc == -70   # (a concave model)
+    with pytest.raises(pkg.UnsupportedConstraint):
+        pkg.get_constraints(2, [("affine", [(0, 1.0)], "Interval", (0.0, 1.0))])       # :298
+    with pytest.raises(pkg.UnsupportedConstraint):
+        pkg.get_constraints(2, [("variable", 0, "EqualTo", 1.0)])                      # :317
+    A, b, G, g, d, u = pkg.get_constraints(2, [])
+    assert A.shape == (0, 2) and G.shape == (0, 2) and (d == -np.inf).all() and (u == np.inf).all()
+    opt = pkg.Optimizer()
+    with pytest.raises(pkg.UnsupportedModel):                                           # norm(V, Inf) == 0 -> LP (:123-126)
+        opt.copy_to_terms(2, [], [(0, 1.0)], 0.0, "MIN_SENSE", [("affine", [(0, 1.0), (1, 1.0)], "EqualTo", 1.0),
+                                                                   ("variable", 0, "GreaterThan", 0.0)])
+    assert opt.is_empty()
+    Q2 = opt.copy_to_terms(3, quad, aff, 3.0, "MIN_SENSE", cons)
+    assert opt.Problem is Q2 and opt.f0 == 3.0 and opt.Sense == "MIN_SENSE" and not opt.is_empty()
+
+
+@pytest.mark.gpu
+def test_optimizer_from_terms_end_to_end_on_the_gpu(pkg):
+    """the reference's own fixture (test/runtests.jl:23-32) expressed as MathOptInterface-style term lists ->
+    copy_to_terms (MOI2QP + getConstraints) -> optimize (solveQP on the GPU) -> the getters"""
+    Vd = [[1 / 100, 1 / 80, 1 / 100], [1 / 80, 1 / 16, 1 / 40], [1 / 100, 1 / 40, 1 / 25]]
+    quad = [(i, j, Vd[i][j]) for i in range(3) for j in range(i, 3)]           # upper triangle: each pair once
+    cons = [("affine", [(0, 1.0), (1, 1.0), (2, 1.0)], "EqualTo", 1.0),
+            ("variable", 0, "Interval", (0.0, 0.7)), ("variable", 1, "GreaterThan", 0.0), ("variable", 2, "Interval", (0.0, 0.7))]
+    opt = pkg.Optimizer(qp_status_fix=True)
+    Q = opt.copy_to_terms(3, quad, [], 0.25, "MIN_SENSE", cons)
+    assert np.array_equal(Q.V, np.array(Vd)) and Q.mc == 1
+    opt.optimize()
+    z, S, it = opt.Results
+    assert S.tolist() == [pkg.UP, pkg.IN, pkg.IN] and it == 2
+    np.testing.assert_allclose(opt.variable_primal(), [0.7, 11 / 210, 52 / 210], rtol=1e-12)
+    assert opt.termination_status() == pkg.TerminationStatus.OPTIMAL
+    assert abs(opt.objective_value() - (z @ np.array(Vd) @ z / 2 + 0.25)) < 1e-15
+
+
 @pytest.mark.gpu
 def test_optimizer_runs_the_reference_kat_on_the_gpu(pkg):
     """MOI.optimize! -> solveQP(Q; settings) (MOIwrapper.jl:165) through the C ABI on the reference's own fixture
