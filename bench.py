@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # quad-cycles per instruction for this kernel)
 VALU_ISSUE_PER_CU = 4 * 2.4e9 / 4.0   # x the device's CU count (256 on MI355X), read from the device at run time
 KERNEL_SOURCES = ["ssqp_wave.hip", "ssqp_kernels.hip", "ssqp_device.h", "ssqp_internal.h", "ssqp_api.hip",
-                  "ssqp_phase1.hip", "ssqp_host.cpp", "../../include/ssqp_hip.h"]
+                  "ssqp_phase1.hip", "ssqp_host.cpp", "../../include/ssqp_hip.h", "ssqp_phase1_wave.h", "ssqp_phase1_wave.hip"]
 
 
 def kernel_source_hash():

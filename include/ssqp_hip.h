@@ -119,6 +119,8 @@ const char *ssqp_last_error(const ssqp_ctx *ctx);
  *   "dense_gamma"     1: the reference's dense formulation (from-scratch factor, gamma pass over all N columns,
  *                     SSQP.jl:322,352) -- the HBM roofline measurement; default 0
  *   "wg_per_cu"       workgroups per CU of the workgroup kernel: 0 = automatic (default), 1, 2
+ *   "phase1_wave"     1 (default): ssqp_phase1_batch_dev_f64 runs one WAVEFRONT per QP where that kernel applies (M + J <= 11,
+ *                     N + J + M + J <= 576; QPs with free variables are left to the workgroup kernel); 0: workgroup kernel only
  *   "lazy_handover"   1: the launch of the workgroup kernel on the wavefront kernel's hand-over list is not queued
  *                     behind it but issued by ssqp_sync (or the next call on the context) and only when the list is
  *                     not empty -- for hosts that keep several contexts busy on different streams (the queued launch
@@ -253,7 +255,9 @@ int ssqp_phase1_batch_f64(int nprob, int N, int M, int J, const double *A, const
                           const ssqp_settings *settingsLP, double *x0, int32_t *S,
                           int32_t *status, int nthreads);
 
-/* The same for a batch whose problem data already sits in HBM: ON the GPU (one workgroup per QP), asynchronous on
+/* The same for a batch whose problem data already sits in HBM: ON the GPU (one wavefront per QP for M + J <= 11 and
+ * N + J + M + J <= 576 -- every column of the LP in the registers of its lane --, one workgroup per QP otherwise and for
+ * QPs with free variables; option "phase1_wave"), asynchronous on
  * `stream`, bit-identical to the host version (same decisions, same summation orders, no FMA contraction), so the loop
  * that follows runs the same passes.  All pointers are device pointers; needs M + J small enough for the basis
  * inverse to fit in LDS (SSQP_ERR_UNSUPPORTED otherwise: use the host version).  dstatus as above. */

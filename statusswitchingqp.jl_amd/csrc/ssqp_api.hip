@@ -40,7 +40,8 @@ struct ssqp_ctx {
     const void *pinnedPtr = nullptr;
     size_t pinnedBytes = 0;
     // grow-only device workspaces
-    DevBuf Ct, rhs, queue, gscratch, fbList, fbList2, fbIter, wscratch, wscratchBig, p1ws, p1wsInt;
+    DevBuf Ct, rhs, queue, gscratch, fbList, fbList2, fbIter, wscratch, wscratchBig, p1ws, p1wsInt, p1queue, p1list;
+    int optPhase1Wave = 1;   // 0: Phase-1 by the workgroup kernel only
     // staging buffers of the host-pointer entry points
     DevBuf hV, hA, hG, hq, hb, hg, hd, hu, hS, hx0, hz, hstatus, hdetail, hstats, hlam, hgam;
     // lazy hand-over: the launch the wavefront kernel may still owe (its hand-over count lands in pinned memory)
@@ -154,7 +155,7 @@ int ssqp_ctx_destroy(ssqp_ctx *c) {
     c->lanes.clear();
     for (hipEvent_t &e : c->evCopy)
         if (e) (void)hipEventDestroy(e), e = nullptr;
-    for (DevBuf *b : {&c->Ct, &c->rhs, &c->queue, &c->gscratch, &c->fbList, &c->fbList2, &c->fbIter, &c->wscratch, &c->wscratchBig, &c->p1ws, &c->p1wsInt, &c->hV, &c->hA, &c->hG, &c->hq, &c->hb, &c->hg,
+    for (DevBuf *b : {&c->Ct, &c->rhs, &c->queue, &c->gscratch, &c->fbList, &c->fbList2, &c->fbIter, &c->wscratch, &c->wscratchBig, &c->p1ws, &c->p1wsInt, &c->p1queue, &c->p1list, &c->hV, &c->hA, &c->hG, &c->hq, &c->hb, &c->hg,
                       &c->hd, &c->hu, &c->hS, &c->hx0, &c->hz, &c->hstatus, &c->hdetail, &c->hstats, &c->hlam, &c->hgam})
         release(*b);
     for (int k = 0; k < ssqp_ctx::EV_RING; ++k) {
@@ -177,6 +178,7 @@ static int *option_slot(ssqp_ctx *c, const char *name) {
     if (!std::strcmp(name, "wave_qp_per_cu")) return &c->optWaveQPC;
     if (!std::strcmp(name, "pin_host_buffers")) return &c->optPinHost;
     if (!std::strcmp(name, "lazy_handover")) return &c->optLazyHandover;
+    if (!std::strcmp(name, "phase1_wave")) return &c->optPhase1Wave;
     return nullptr;
 }
 int ssqp_ctx_set_option(ssqp_ctx *c, const char *name, int value) {
@@ -188,7 +190,8 @@ int ssqp_ctx_set_option(ssqp_ctx *c, const char *name, int value) {
     if ((slot == &c->optWgPerCU && (value < 0 || value > ssqp::MAX_WG_PER_CU)) ||
         (slot == &c->optWaveQPC && (value < 0 || value > 8)) ||
         (slot == &c->optWaveKernel && (value < 0 || value > 2)) ||
-        ((slot == &c->optDenseGamma || slot == &c->optIncremental || slot == &c->optPinHost || slot == &c->optLazyHandover) &&
+        ((slot == &c->optDenseGamma || slot == &c->optIncremental || slot == &c->optPinHost || slot == &c->optLazyHandover ||
+          slot == &c->optPhase1Wave) &&
          (value != 0 && value != 1))) {
         c->err = std::string("option value out of range: ") + name;
         return SSQP_ERR_ARG;
@@ -742,9 +745,26 @@ int ssqp_phase1_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const
     }
     if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return SSQP_ERR_HIP;
     const size_t wd = ssqp::phase1_ws_doubles(N, M, J), wi = ssqp::phase1_ws_ints(N, M, J);
+    hipStream_t s = (hipStream_t)stream;
+    // the one-wavefront-per-QP kernel takes the shapes it is built for (M + J <= 11, N + J + M + J <= 576); what it leaves
+    // on its list -- QPs with free variables -- goes to the workgroup kernel, which a bounded grid works off (an empty list:
+    // that grid exits at once)
+    const bool wave = c->optPhase1Wave && ssqp::phase1_wave_applies(N, M, J);
+    const unsigned int *listCount = nullptr;
+    const int *list = nullptr;
+    if (wave) {
+        if (!ensure(c, c->p1queue, 64) || !ensure(c, c->p1list, (size_t)nprob * 4)) return SSQP_ERR_ALLOC;
+        if (!hip_ok(c, hipMemsetAsync(c->p1queue.p, 0, 64, s), "hipMemsetAsync")) return SSQP_ERR_HIP;
+        if (!hip_ok(c, ssqp::launch_phase1_wave(nprob, N, M, J, dA, dG, db, dg, dd, du, st->tol, dx0, dS, dstatus,
+                                                (unsigned int *)c->p1queue.p, (int *)c->p1list.p, s), "phase-1 wave launch"))
+            return SSQP_ERR_HIP;
+        listCount = (const unsigned int *)c->p1queue.p;
+        list = (const int *)c->p1list.p;
+    }
+    // (the workspaces are indexed by problem id: a listed QP may be any of them)
     if (!ensure(c, c->p1ws, (size_t)nprob * wd * 8) || !ensure(c, c->p1wsInt, (size_t)nprob * wi * 4)) return SSQP_ERR_ALLOC;
     return hip_ok(c, ssqp::launch_phase1(nprob, N, M, J, dA, dG, db, dg, dd, du, st->tol, dx0, dS, dstatus,
-                                         (double *)c->p1ws.p, wd, (int *)c->p1wsInt.p, wi, (hipStream_t)stream),
+                                         (double *)c->p1ws.p, wd, (int *)c->p1wsInt.p, wi, listCount, list, 2 * c->numCU, s),
                   "phase-1 launch") ? SSQP_OK : SSQP_ERR_HIP;
 }
 

@@ -178,7 +178,14 @@ size_t phase1_ws_ints(int N, int M, int J);
 size_t phase1_lds_bytes(int M, int J);
 hipError_t launch_phase1(int nprob, int N, int M, int J, const double *A, const double *G, const double *b, const double *g,
                          const double *d, const double *u, double tol, double *x0, int32_t *S, int32_t *status, double *ws,
-                         size_t wsStride, int *wsInt, size_t wsIntStride, hipStream_t stream);
+                         size_t wsStride, int *wsInt, size_t wsIntStride, const unsigned int *listCount, const int *list, int gridCap,
+                         hipStream_t stream);
+// ---- Phase-1, one wavefront per QP (ssqp_phase1_wave.hip): M + J <= 11 rows and N + J + M + J <= 576 columns; a QP with a
+// free variable is left on (fbCount, fbList) for the workgroup kernel
+bool phase1_wave_applies(int N, int M, int J);
+hipError_t launch_phase1_wave(int nprob, int N, int M, int J, const double *A, const double *G, const double *b, const double *g,
+                              const double *d, const double *u, double tol, double *x0, int32_t *S, int32_t *status,
+                              unsigned int *fbCount, int *fbList, hipStream_t stream);
 
 }  // namespace ssqp
 #endif

@@ -316,12 +316,12 @@ struct P1Params {
     int *wsInt;        // nprob integer workspaces of wsIntStride ints
     size_t wsIntStride;
     int ldsVec;        // 1: the N1-vectors every pass reads (S1, nonbasic, x, colnorm, sdot) live in LDS (they fit)
+    // the QPs the one-wavefront-per-QP kernel (ssqp_phase1_wave.hip) did not take: problem ids and their count (null: all)
+    const unsigned int *listCount;
+    const int *list;
 };
 
-__global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (four workgroups per CU: 1,024 QPs resident)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int prob = blockIdx.x;
-    if (prob >= P.nprob) return;
+__device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob, unsigned char *smem) {
     const int tid = threadIdx.x;
     P1_DECL;
     const int N = P.N, M = P.M, J = P.J, M0 = M + J;
@@ -860,6 +860,16 @@ __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (
     for (int t = tid; t < nup; t += NT1) x0[upperOnly[t]] = -x0[upperOnly[t]];  // (statuses stay: SSQP.jl:552-557 is a no-op)
 }
 
+__global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (four workgroups per CU: 1,024 QPs resident)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // one QP per workgroup; on a list (what the wavefront kernel left) a bounded grid strides over it
+    const int n = P.list ? (int)*P.listCount : P.nprob;
+    for (int it = blockIdx.x; it < n; it += gridDim.x) {
+        phase1_one_wg(P, P.list ? P.list[it] : it, smem);
+        __syncthreads();
+    }
+}
+
 }  // namespace p1
 
 size_t phase1_ws_doubles(int N, int M, int J) {
@@ -881,8 +891,10 @@ static size_t phase1_lds_bytes_vec(int N, int M, int J) {
 }
 hipError_t launch_phase1(int nprob, int N, int M, int J, const double *A, const double *G, const double *b, const double *g,
                          const double *d, const double *u, double tol, double *x0, int32_t *S, int32_t *status, double *ws,
-                         size_t wsStride, int *wsInt, size_t wsIntStride, hipStream_t stream) {
+                         size_t wsStride, int *wsInt, size_t wsIntStride, const unsigned int *listCount, const int *list, int gridCap,
+                         hipStream_t stream) {
     p1::P1Params P;
+    P.listCount = listCount; P.list = list;
     P.nprob = nprob; P.N = N; P.M = M; P.J = J;
     P.A = A; P.G = G; P.b = b; P.g = g; P.d = d; P.u = u;
     P.tol = tol;
@@ -898,7 +910,8 @@ hipError_t launch_phase1(int nprob, int N, int M, int J, const double *A, const 
     static unsigned long long ldsSet = 0ull;
     hipError_t e = allow_full_lds(reinterpret_cast<const void *>(&p1::ssqp_phase1_kernel), &ldsSet);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(p1::ssqp_phase1_kernel, dim3(nprob), dim3(p1::NT1), lds, stream, P);
+    const int grid = (list && gridCap > 0 && gridCap < nprob) ? gridCap : nprob;
+    hipLaunchKernelGGL(p1::ssqp_phase1_kernel, dim3(grid), dim3(p1::NT1), lds, stream, P);
     return hipGetLastError();
 }
 

@@ -363,9 +363,10 @@ constexpr int RING_BYTES = 16 * 1024;
 
 // One LDS-DMA load, 16 B per lane: global address = the UNIFORM 64-bit base `sbase` + this lane's byte offset `voff`;
 // LDS destination = M0 base `lds_dst` + lane * 16.  The base travels in a scalar register pair and the per-lane offsets
-// of a stream are loop-invariant, so a piece costs s_mov m0 + s_nop + the load.  M0 is NOT saved: the statement lists it
-// as clobbered, and nothing else in these kernels uses it (no ds_gws, no s_movrel, no LDS-direct; tests/test_capi_cpu.py
-// checks the built code objects for that).
+// of a stream are loop-invariant, so a piece costs s_mov m0 + s_nop + the load.  M0 is NOT saved, and it cannot be
+// declared clobbered either (LLVM treats m0 as a reserved register and ignores -- with a warning -- a clobber of it):
+// nothing else in these kernels uses it (no ds_gws, no s_movrel, no LDS-direct), and tests/test_capi_cpu.py checks the
+// built code objects for exactly that; the test fails, not skips, where the library was built.
 __device__ __forceinline__ const double *uni_ptr(const double *p) {  // a uniform pointer, pinned to a scalar register pair
     const unsigned long long a = (unsigned long long)p;
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
@@ -376,7 +377,7 @@ __device__ __forceinline__ void glds16_s(const void *sbase, unsigned voff, unsig
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0"
                  :
                  : "s"(sbase), "v"(voff), "s"(lds_dst)
-                 : "memory", "m0");
+                 : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() {

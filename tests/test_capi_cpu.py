@@ -153,8 +153,8 @@ def _device_disassemblies():
 
 
 def test_m0_belongs_to_the_lds_dma_loads():
-    """The LDS-DMA loads of the big-factor build (glds16_s in ssqp_wave.hip) set M0 and do not restore it (the asm
-    statement lists m0 as clobbered): nothing else in the library's kernels may use M0.  Checked on the code objects of
+    """The LDS-DMA loads of the big-factor build (glds16_s in ssqp_wave.hip) set M0 and do not restore it (LLVM ignores
+    a clobber of the reserved m0): nothing else in the library's kernels may use M0.  Checked on the code objects of
     the built device objects."""
     n_dma = n_load = 0
     for o, ins3 in _device_disassemblies():
