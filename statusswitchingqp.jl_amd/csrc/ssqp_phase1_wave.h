@@ -35,6 +35,30 @@ namespace p1w {
 
 constexpr double INF = __builtin_huge_val();
 
+// ---- diagnostic build only (-DSSQP_PHASE_PROFILE): cycles per phase, accumulated in registers, flushed once per QP ----
+#ifdef SSQP_PHASE_PROFILE
+static __device__ unsigned long long g_p1wphase[16];
+#define W1_DECL unsigned long long w1t = __builtin_amdgcn_s_memtime(); unsigned long long w1a[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define W1_STAMP(slot)                                                   \
+    do {                                                                 \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();      \
+        w1a[slot] += t_ - w1t;                                           \
+        w1t = __builtin_amdgcn_s_memtime();                              \
+    } while (0)
+#define W1_COUNT(slot) w1a[slot] += 1
+#define W1_FLUSH()                                                                                                     \
+    do {                                                                                                               \
+        if ((threadIdx.x & 63) == 0)                                                                                   \
+            for (int k_ = 0; k_ < 16; ++k_)                                                                            \
+                (void)__hip_atomic_fetch_add(&g_p1wphase[k_], w1a[k_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    \
+    } while (0)
+#else
+#define W1_DECL do { } while (0)
+#define W1_STAMP(slot) do { } while (0)
+#define W1_COUNT(slot) do { } while (0)
+#define W1_FLUSH() do { } while (0)
+#endif
+
 struct Params {
     int nprob, N, M, J;
     const double *A, *G, *b, *g, *d, *u;   // per problem, back to back (A: M x N, G: J x N, column-major)
@@ -46,11 +70,11 @@ struct Params {
     int *fbList;
 };
 
-// LDS of one wavefront, in doubles: lo, hi by variable id (64 NC each), the basis matrix by columns and the MC x MC
-// transposes, MC scratch, then ints
+// LDS of one wavefront, in doubles: lo, hi, x, ||A[:,k]|| by variable id (64 NC each), the basis matrix by columns and the MC x MC
+// transposes, the cached terms of the xb sum (TCAP slots of MC), MC scratch, then ints
 template <int NC, int MC>
 __host__ __device__ constexpr int lds_doubles() {
-    return 2 * 64 * NC + 2 * MC * MC + 2 * MC + 2 * MC;  // (+ 2 MC doubles' worth of ints)
+    return 4 * 64 * NC + 2 * MC * MC + 64 * MC + 64 * ((MC + 2) & ~1) + 2 * MC + 2 * MC + 32;  // (64 = TCAP; the tail: ints)
 }
 
 template <int NC>
@@ -80,51 +104,51 @@ __device__ __forceinline__ void col_set(double (&v)[NC], int k, double x) {  // 
 template <int MC>
 __device__ __forceinline__ bool invert_lu_regs(double (&col)[MC], int n) {
 #pragma clang fp contract(off)
+    // Straight-line code: every step runs for every k < MC with selects instead of branches (a branch per step makes the
+    // register allocator re-shuffle the whole column at every join -- a third of the instructions of the first version).
+    // Rows and lanes n .. MC - 1 are ZERO (the LP's columns are zero-padded; the lanes are cleared here): a padded row or
+    // lane takes part with zeros, which change no bit of a real entry, and a padded step has its reciprocal forced to 0.
     const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < MC; ++i) col[i] = (lane < n) ? col[i] : 0.0;
     int pv[MC];
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < MC; ++k) {
-        pv[k] = k;
-        if (k < n && ok) {  // uniform
-            double ck[MC];
+        const bool step = k < n;  // uniform
+        // the FIRST largest |a(i, k)|, i = k .. n - 1 (the host's strict ">" scan): every lane scans its own column, lane k's
+        // verdict counts (per-lane arithmetic: the scalar unit has no f64 compare)
+        int pl = k;
+        double best = fabs(col[k]);
 #pragma unroll
-            for (int i = k; i < MC; ++i) ck[i] = readlane_f64(col[i], k);
-            int p = k;  // the FIRST largest |a(i, k)|, i = k .. n - 1 (the host's strict ">" scan)
-            double best = fabs(ck[k]);
+        for (int i = k + 1; i < MC; ++i) {
+            const double v = fabs(col[i]);
+            const bool gt = v > best;
+            best = gt ? v : best;
+            pl = gt ? i : pl;
+        }
+        const int p = __builtin_amdgcn_readlane(pl, k);   // (a padded step: every entry is zero, so p = k)
+        best = readlane_f64(best, k);
+        ok = ok && (!step || best != 0.0);
+        pv[k] = p;
+        {   // rows k and p change places in every column (p == k: nothing matches)
+            const double ak = col[k];
+            double ap = ak;
 #pragma unroll
-            for (int i = k + 1; i < MC; ++i)
-                if (i < n) {
-                    const double v = fabs(ck[i]);
-                    if (v > best) best = v, p = i;
-                }
-            p = __builtin_amdgcn_readfirstlane(p);
-            if (best == 0.0) {
-                ok = false;
-            } else {
-                pv[k] = p;
-                if (p != k) {  // rows k and p change places in every column (uniform p: one branch per candidate row)
-#pragma unroll
-                    for (int i = k + 1; i < MC; ++i)
-                        if (i == p) {
-                            const double t = col[k];
-                            col[k] = col[i];
-                            col[i] = t;
-                            const double tc = ck[k];
-                            ck[k] = ck[i];
-                            ck[i] = tc;
-                        }
-                }
-                const double r = 1.0 / ck[k];
-                const double akj = col[k];
-#pragma unroll
-                for (int i = k + 1; i < MC; ++i)
-                    if (i < n) {
-                        const double li = ck[i] * r;                       // a(i, k) *= r
-                        const double upd = col[i] - li * akj;              // a(i, j) -= a(i, k) * a(k, j)   (j > k)
-                        col[i] = (lane == k) ? li : ((lane > k) ? upd : col[i]);
-                    }
+            for (int i = k + 1; i < MC; ++i) {
+                ap = (i == p) ? col[i] : ap;
+                col[i] = (i == p) ? ak : col[i];
             }
+            col[k] = ap;
+        }
+        const double rq = 1.0 / readlane_f64(col[k], k);
+        const double r = step ? rq : 0.0;
+        const double akj = col[k];
+#pragma unroll
+        for (int i = k + 1; i < MC; ++i) {
+            const double li = readlane_f64(col[i], k) * r;           // a(i, k) *= r
+            const double upd = col[i] - li * akj;                    // a(i, j) -= a(i, k) * a(k, j)   (j > k)
+            col[i] = (lane > k) ? upd : ((lane == k) ? li : col[i]);
         }
     }
     if (!ok) return false;
@@ -132,35 +156,23 @@ __device__ __forceinline__ bool invert_lu_regs(double (&col)[MC], int n) {
     // unit vector has its 1 where that sequence of swaps sends index c
     int pos = lane;
 #pragma unroll
-    for (int k = 0; k < MC; ++k)
-        if (k < n && pv[k] != k) pos = (pos == k) ? pv[k] : ((pos == pv[k]) ? k : pos);
+    for (int k = 0; k < MC; ++k) pos = (pos == k) ? pv[k] : ((pos == pv[k]) ? k : pos);   // (pv[k] == k: no change)
     double xc[MC];
 #pragma unroll
     for (int i = 0; i < MC; ++i) xc[i] = (i == pos) ? 1.0 : 0.0;
 #pragma unroll
     for (int k = 0; k < MC; ++k) {  // forward: x[i] -= L(i, k) x[k]  for i > k
-        if (k < n) {
 #pragma unroll
-            for (int i = k + 1; i < MC; ++i)
-                if (i < n) {
-                    const double l = readlane_f64(col[i], k);
-                    xc[i] -= l * xc[k];
-                }
-        }
+        for (int i = k + 1; i < MC; ++i) xc[i] -= readlane_f64(col[i], k) * xc[k];
     }
 #pragma unroll
     for (int kk = 0; kk < MC; ++kk) {  // backward: x[k] /= U(k, k), then x[i] -= U(i, k) x[k]  for i < k
         const int k = MC - 1 - kk;
-        if (k < n) {
-            const double ukk = readlane_f64(col[k], k);
-            xc[k] /= ukk;
+        const double q = xc[k] / readlane_f64(col[k], k);
+        xc[k] = (k < n) ? q : 0.0;
 #pragma unroll
-            for (int i = 0; i < MC; ++i)
-                if (i < k) {
-                    const double u = readlane_f64(col[i], k);
-                    xc[i] -= u * xc[k];
-                }
-        }
+        for (int i = 0; i < MC; ++i)
+            if (i < k) xc[i] -= readlane_f64(col[i], k) * xc[k];
     }
 #pragma unroll
     for (int i = 0; i < MC; ++i) col[i] = xc[i];
@@ -169,10 +181,18 @@ __device__ __forceinline__ bool invert_lu_regs(double (&col)[MC], int n) {
 
 // One QP.  `lds`: lds_doubles<NC, MC>() doubles of this wavefront's LDS.  Returns false when the QP was not taken (it has
 // free variables and now sits on P.fbList); otherwise x0, S and status are written.
+// Padding: rows M0 .. MC - 1 of every column, of inv(B) and of the row vectors are exactly +0.0, so the loops over rows
+// carry no guard on M0: a padded row adds 0.0 * 0.0 = +0.0 to a sum that started at +0.0 and therefore is never -0.0 (x + y
+// = -0.0 needs x = y = -0.0) -- no bit of any sum changes.
+constexpr int TCAP = 64;
+#ifndef RGBIG
+#define RGBIG 1
+#endif   // nonbasic columns at a nonzero value whose xb terms are cached (more: recomputed every pass)
 template <int NC, int MC>
 __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds) {
 #pragma clang fp contract(off)
     const int lane = threadIdx.x & 63;
+    W1_DECL;
     const int N = P.N, M = P.M, J = P.J, M0 = M + J;
     const int N0 = N + J, N1 = N0 + M0;
     const double *A = P.A + (size_t)prob * M * N;
@@ -185,15 +205,22 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
     double *x0 = P.x0 + (size_t)prob * N;
     int32_t *S = P.S + (size_t)prob * (N + J);
 
-    double *lo = lds, *hi = lo + 64 * NC;
-    double *T = hi + 64 * NC;            // MC x MC: columns on their way between lanes
+    // by variable id k (lane k & 63 owns it): bounds, value, column norm -- what a pass touches once at most stays out of
+    // the register file, which the LP's columns fill
+    double *lo = lds, *hi = lo + 64 * NC, *xL = hi + 64 * NC, *nL = xL + 64 * NC;
+    double *T = nL + 64 * NC;            // MC x MC: columns on their way between lanes
     double *Bc = T + MC * MC;            // MC x MC: column j of the basis matrix A1[:, basis[j]] at Bc[j * MC ..]
-    double *sg = Bc + MC * MC;           // MC: signs of the artificial columns
+    double *tl = Bc + MC * MC;           // TCAP x MC: cached terms Y[:,k] x_k of the xb sum, one slot per listed column
+    constexpr int MCP = (MC + 2) & ~1;   // a listed column in LDS: its MC entries, then x_k (16-byte rows)
+    double *AL = tl + TCAP * MC;         // TCAP x MCP: the listed columns side by side while their terms are formed
+    double *sg = AL + TCAP * MCP;        // MC: signs of the artificial columns
     int *ib = reinterpret_cast<int *>(sg + 2 * MC);  // 2 MC ints
+    int *ib2 = ib + 2 * MC;              // TCAP ints: column ids of the list
 
     // ---- the LP of initQP (SSQP.jl:484-526): columns [A; G | slack | artificials], this lane's columns in registers
-    double a[NC][MC], sd[NC], xv[NC], nrm[NC];
-    unsigned stw = 0, nbw = 0, upw = 0;   // per column slot: status (2 bits: IN 0, DN 1, UP 2), nonbasic, (-inf, u] variable
+    double a[NC][MC], sd[NC];
+    // per column slot: status (2 bits: IN 0, DN 1, UP 2), nonbasic, (-inf, u] variable, value x != 0
+    unsigned stw = 0, nbw = 0, upw = 0, nzw = 0;
     bool anyFree = false;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -227,7 +254,8 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
         }
         stw |= 1u << (2 * c);                 // DN
         if (k < N0) nbw |= 1u << c;
-        xv[c] = lok;                          // x[k] = lo[k]  (every nonbasic starts at its lower bound)
+        xL[k] = lok;                          // x[k] = lo[k]  (every nonbasic starts at its lower bound)
+        if (lok != 0.0) nzw |= 1u << c;
         sd[c] = 0.0;
     }
     if (__ballot(anyFree) != 0ull) {
@@ -240,24 +268,24 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
     wave_sync();
     // rows: lane r < M0 owns row r of the basis
     const int rr = lane < M0 ? lane : 0;
-    const double rhs = (M0 > 0) ? ((rr < M) ? b[rr < M ? rr : 0] : g[rr >= M ? rr - M : 0]) : 0.0;
+    double rhs = 0.0;
+    if (lane < M0) rhs = (lane < M) ? b[lane < M ? lane : 0] : g[lane >= M ? lane - M : 0];
     // start = sum over the columns k < N0 with lo != 0, ascending, of A1[:,k] * lo[k]   (SSQP.jl:511-526)
     double start = 0.0;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int k = lane + 64 * c;
-        unsigned long long m = __ballot(k < N0 && xv[c] != 0.0);
+        unsigned long long m = __ballot(k < N0 && ((nzw >> c) & 1u));
         while (m) {  // uniform
             const int l = __ffsll((long long)m) - 1;
             m &= m - 1;
-            const double lk = readlane_f64(xv[c], l);
+            const double lk = xL[l + 64 * c];
             double ar = 0.0;
 #pragma unroll
-            for (int t = 0; t < MC; ++t)
-                if (t < M0) {
-                    const double v = readlane_f64(a[c][t], l);
-                    ar = (lane == t) ? v : ar;
-                }
+            for (int t = 0; t < MC; ++t) {
+                const double v = readlane_f64(a[c][t], l);
+                ar = (lane == t) ? v : ar;
+            }
             start += ar * lk;
         }
     }
@@ -270,7 +298,7 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
         ivr[t] = (lane == t && lane < M0) ? sgn : 0.0;   // invB = diag(sgn)
         if (lane < MC) Bc[lane * MC + t] = ivr[t];       // column `lane` of the basis matrix: the artificial column
     }
-    double xb = fabs(start - rhs);
+    double xb = (lane < M0) ? fabs(start - rhs) : 0.0;
     int bas = N0 + rr;
     double blo = 0.0, bhi = INF;
 #pragma unroll
@@ -285,38 +313,64 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
         }
         double s = 0.0;
 #pragma unroll
-        for (int r = 0; r < MC; ++r)
-            if (r < M0) s += a[c][r] * a[c][r];
-        nrm[c] = sqrt(s);
+        for (int r = 0; r < MC; ++r) s += a[c][r] * a[c][r];
+        nL[k] = sqrt(s);
     }
 
     // Y = invB * A[:, nonbasic] is never stored (as in ssqp_phase1.hip): the pricing needs Y[:,k] . c[basis], formed
-    // here for every column this lane owns, rows in the host's order; row r of invB and c[basis[r]] come out of lane r as
-    // scalars
+    // here for every column this lane owns, rows in the host's order; row r of invB comes out of lane r as scalars.
+    // c[basis[r]] is 1 for an artificial variable and 0 otherwise.  A row with c = 0 adds s * 0.0 = +-0.0 to a sum that
+    // started at +0.0 and is never -0.0: it changes no bit of it and is skipped -- more than half of the rows, on average
+    // (only a row sum that is Inf / NaN would have left a NaN behind).  The rows that count go up to three at a time, so that
+    // an entry of the LP (half of them live in the accumulator half of the register file) is fetched once per group.
+    constexpr int RG = (NC * MC > 60) ? RGBIG : 3;   // rows per round (the accumulators of a round: RG x NC doubles)
     auto refreshY = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) sd[c] = 0.0;
-        for (int r = 0; r < M0; ++r) {
-            // c[basis[r]] is 1 for an artificial variable and 0 otherwise.  A row with c = 0 adds s * 0.0 = +-0.0 to a sum that
-            // started at +0.0 and is never -0.0 (x + y = -0.0 needs x = y = -0.0): it changes no bit of it and is skipped --
-            // more than half of the rows, on average (only a row sum that is Inf / NaN would have left a NaN behind)
-            if (__builtin_amdgcn_readlane(bas, r) < N0) continue;
-            const double cb = 1.0;
-            double s[NC];
+        unsigned long long rows = __ballot(lane < M0 && bas >= N0);
+        while (rows) {  // uniform: up to three artificial rows per round, ascending
+            int r3[RG];
+            bool on[RG];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) s[c] = 0.0;
+            for (int q = 0; q < RG; ++q) {
+                on[q] = rows != 0ull;
+                r3[q] = on[q] ? __ffsll((long long)rows) - 1 : 0;
+                rows &= rows - 1;   // (0 stays 0)
+            }
+            double s[RG][NC];
 #pragma unroll
-            for (int t = 0; t < MC; ++t)
-                if (t < M0) {
-                    const double iv = readlane_f64(ivr[t], r);
+            for (int q = 0; q < RG; ++q)
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) s[c] += iv * a[c][t];
+                for (int c = 0; c < NC; ++c) s[q][c] = 0.0;
+#pragma unroll
+            for (int t = 0; t < MC; ++t) {
+                double iv[RG];
+#pragma unroll
+                for (int q = 0; q < RG; ++q) iv[q] = readlane_f64(ivr[t], r3[q]);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const double act = a[c][t];
+#pragma unroll
+                    for (int q = 0; q < RG; ++q) s[q][c] += iv[q] * act;
                 }
+            }
 #pragma unroll
-            for (int c = 0; c < NC; ++c) sd[c] += s[c] * cb;
+            for (int q = 0; q < RG; ++q) {
+                const double cb = on[q] ? 1.0 : 0.0;   // (a round's unused places repeat row 0 with weight 0: + +-0.0)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) sd[c] += s[q][c] * cb;
+            }
         }
     };
     refreshY();
+    W1_STAMP(0);  // set-up
+
+    // ---- the xb sum's terms Y[:,k] x_k of the nonbasic columns at a nonzero value, cached between basis changes: lane p
+    // holds the column id (kkv) and the LDS slot (ordv) of the p-th listed column in ascending order, lane r reads
+    // its row of a slot.  A bound flip touches one term; the sum is re-added in order every pass.
+    int kkv = 0x7fffffff, ordv = 0, cnt = 0;
+    unsigned long long used = 0ull;
+    bool rebuild = true, cached = false;
 
     int status = 1;
     long loop = 0;
@@ -328,6 +382,7 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
             status = -1;
             break;
         }
+        W1_COUNT(14);
         const bool bland = loop > N1;
         // ---- price: signed reduced costs, the entering candidate (first maximum of h / ||A[:,k]||; Bland: first candidate)
         double best = -INF;
@@ -337,16 +392,19 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
             const int k = lane + 64 * c;
             const double ck = k >= N0 ? 1.0 : 0.0;  // (= cost[k]: the Phase-1 objective is the sum of the artificials)
             double hv = ck - sd[c];
-            if (((stw >> (2 * c)) & 3u) == (unsigned)SSQP_DN) hv = -hv;
-            if (((nbw >> c) & 1u) && hv > tol) {
-                const double v = bland ? 0.0 : hv / nrm[c];
-                if (v > best) best = v, bidx = k;   // (ascending k inside the lane: the first maximum stays)
-            }
+            hv = (((stw >> (2 * c)) & 3u) == (unsigned)SSQP_DN) ? -hv : hv;
+            const bool candk = ((nbw >> c) & 1u) && hv > tol;
+            double v = hv / nL[k];
+            v = bland ? 0.0 : v;
+            const bool take = candk && v > best;   // (ascending k inside the lane: the first maximum stays)
+            best = take ? v : best;
+            bidx = take ? k : bidx;
         }
         {
             const KeyMin km = wave_keymin(KeyMin{-best, bidx});
             bidx = km.ord;
         }
+        W1_STAMP(1);  // pricing + first maximum
         if (bidx == 0x7fffffff) break;  // no improving candidate: optimal
         const int k = bidx, lk = k & 63, ck_ = k >> 6;
         // ---- the entering column, as scalars; p = invB * A[:,k]: lane r forms row r
@@ -357,13 +415,11 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
         for (int c = 0; c < NC; ++c)
             if (ck_ == c) {
 #pragma unroll
-                for (int t = 0; t < MC; ++t)
-                    if (t < M0) ak[t] = readlane_f64(a[c][t], lk);
+                for (int t = 0; t < MC; ++t) ak[t] = readlane_f64(a[c][t], lk);
             }
         double p = 0.0;
 #pragma unroll
-        for (int t = 0; t < MC; ++t)
-            if (t < M0) p += ivr[t] * ak[t];
+        for (int t = 0; t < MC; ++t) p += ivr[t] * ak[t];
         const bool fromLower = ((((unsigned)__builtin_amdgcn_readlane((int)stw, lk)) >> (2 * ck_)) & 3u) == (unsigned)SSQP_DN;
         const double loK = lo[k], hiK = hi[k];
         const double rangeK = hiK - loK;
@@ -398,14 +454,52 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
             else if (lr <= -rangeK) action = -2;
             else action = lrow + 1, leaveStatus = lto;
         }
+        W1_STAMP(2);  // entering column + ratio test
         if (unbounded) {
             status = 3;
             break;
         }
         if (action < 0) {  // bound flip of the entering variable
             const unsigned ns = action == -1 ? (unsigned)SSQP_UP : (unsigned)SSQP_DN;
-            if (lane == lk) stw = (stw & ~(3u << (2 * ck_))) | (ns << (2 * ck_));
-            col_set<NC>(xv, k, action == -1 ? hiK : loK);
+            const double xnew = action == -1 ? hiK : loK;
+            const double xold = xL[k];
+            if (lane == lk) {
+                stw = (stw & ~(3u << (2 * ck_))) | (ns << (2 * ck_));
+                nzw = (nzw & ~(1u << ck_)) | ((xnew != 0.0 ? 1u : 0u) << ck_);
+                xL[k] = xnew;
+            }
+            if (cached && !rebuild) {  // the one term of the cached xb sum that changes: Y[:,k] = p, the value just formed
+                const bool was = xold != 0.0, is = xnew != 0.0;
+                if (was) {  // (uniform) in the list: its place and slot
+                    const int at = __ffsll((long long)__ballot(lane < cnt && kkv == k)) - 1;
+                    const int slot = __builtin_amdgcn_readlane(ordv, at);
+                    if (is) {
+                        if (lane < MC) tl[slot * MC + lane] = p * xnew;
+                    } else {   // leaves the list: the later entries move down
+                        used &= ~(1ull << slot);
+                        const int kn = __builtin_amdgcn_update_dpp(0x7fffffff, kkv, 0x130, 0xF, 0xF, false);
+                        const int on = __builtin_amdgcn_update_dpp(0, ordv, 0x130, 0xF, 0xF, false);
+                        kkv = (lane >= at) ? kn : kkv;
+                        ordv = (lane >= at) ? on : ordv;
+                        cnt -= 1;
+                    }
+                } else if (is) {
+                    if (cnt >= TCAP) {
+                        cached = false;   // (no room: this QP goes back to recomputing the terms every pass)
+                    } else {
+                        const int at = __popcll(__ballot(lane < cnt && kkv < k));
+                        const int slot = __ffsll((long long)~used) - 1;
+                        used |= 1ull << slot;
+                        if (lane < MC) tl[slot * MC + lane] = p * xnew;
+                        const int kp = __builtin_amdgcn_update_dpp(0x7fffffff, kkv, 0x138, 0xF, 0xF, false);
+                        const int op = __builtin_amdgcn_update_dpp(0, ordv, 0x138, 0xF, 0xF, false);
+                        kkv = (lane > at) ? kp : ((lane == at) ? k : kkv);
+                        ordv = (lane > at) ? op : ((lane == at) ? slot : ordv);
+                        cnt += 1;
+                    }
+                }
+                wave_sync();
+            }
         } else {
             const int row = action - 1;
             const int leaving = __builtin_amdgcn_readlane(bas, row);
@@ -418,8 +512,7 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
             if (lane == row) bas = k;
             int rank = 0;
 #pragma unroll
-            for (int i = 0; i < MC; ++i)
-                if (i < M0) rank += (__builtin_amdgcn_readlane(bas, i) < bas) ? 1 : 0;
+            for (int i = 0; i < MC; ++i) rank += (i < M0 && __builtin_amdgcn_readlane(bas, i) < bas) ? 1 : 0;
             if (lane < M0) {
                 ib[rank] = bas;
 #pragma unroll
@@ -436,10 +529,13 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
             blo = lo[bas];
             bhi = hi[bas];
             wave_sync();
+            W1_STAMP(3);  // basis sort + columns
+            W1_COUNT(15);
             if (!invert_lu_regs<MC>(col, M0)) {  // lu() of the reference throws (Simplex.jl:590)
                 status = -1;
                 break;
             }
+            W1_STAMP(4);  // inv(lu(B))
             // lane j holds column j of the inverse; row r goes to lane r
             if (lane < M0) {
 #pragma unroll
@@ -459,43 +555,115 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
                 if (lane == ll) {
                     stw = (stw & ~(3u << (2 * lc))) | ((unsigned)leaveStatus << (2 * lc));
                     nbw |= 1u << lc;
+                    nzw = (nzw & ~(1u << lc)) | ((newx != 0.0 ? 1u : 0u) << lc);
+                    xL[leaving] = newx;
                 }
-                col_set<NC>(xv, leaving, newx);
             }
+            W1_STAMP(5);  // rows of the inverse, statuses
             refreshY();
+            rebuild = true;
+            W1_STAMP(6);  // Y . c
         }
         // ---- xb = invB * b - Y * x[nonbasic]: the nonbasic columns at a nonzero value, ascending, one rounded multiply and
         // one rounded add per term (Simplex.jl:599)
         double a2 = 0.0;
+        if (rebuild || !cached) {  // every term anew (inv(B) has changed)
+            // the listed columns, ascending: place of this lane's column of slot c in the list
+            int n = 0;
+            unsigned long long mc[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            unsigned long long m = __ballot(((nbw >> c) & 1u) && xv[c] != 0.0);
-            while (m) {  // uniform
-                const int l = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const double xk = readlane_f64(xv[c], l);
-                double y = 0.0;
+            for (int c = 0; c < NC; ++c) {
+                mc[c] = __ballot(((nbw & nzw) >> c) & 1u);
+                n += __popcll(mc[c]);
+            }
+            if (n <= TCAP) {
+                // through LDS: the owners put their listed columns (and x_k) side by side in list order -- every listed
+                // column of a slot at once --, then lane r reads a column's entries from ONE address each (a broadcast read)
+                // and forms row r of Y[:,k] x_k: a tenth of the v_readlane traffic of fetching them lane by lane
+                int base = 0;
 #pragma unroll
-                for (int t = 0; t < MC; ++t)
-                    if (t < M0) y += ivr[t] * readlane_f64(a[c][t], l);
-                a2 += y * xk;
+                for (int c = 0; c < NC; ++c) {
+                    if (mc[c]) {  // uniform
+                        const int at = base + __popcll(mc[c] & ((1ull << lane) - 1ull));
+                        if ((mc[c] >> lane) & 1ull) {
+#pragma unroll
+                            for (int t = 0; t < MC; ++t) AL[at * MCP + t] = a[c][t];
+                            AL[at * MCP + MC] = xL[lane + 64 * c];
+                            ib2[at] = lane + 64 * c;
+                        }
+                        base += __popcll(mc[c]);
+                    }
+                }
+                wave_sync();
+                kkv = (lane < n) ? ib2[lane < n ? lane : 0] : 0x7fffffff;
+                for (int j = 0; j < n; j += 2) {  // (two columns per round: two independent chains of dependent adds)
+                    const bool two = j + 1 < n;
+                    const double *__restrict__ c0 = AL + j * MCP, *__restrict__ c1 = AL + (two ? j + 1 : j) * MCP;
+                    double y0 = 0.0, y1 = 0.0;
+#pragma unroll
+                    for (int t = 0; t < MC; ++t) {
+                        y0 += ivr[t] * c0[t];
+                        y1 += ivr[t] * c1[t];
+                    }
+                    const double t0 = y0 * c0[MC], t1 = y1 * c1[MC];
+                    a2 += t0;
+                    a2 += two ? t1 : 0.0;   // (+0.0 on a sum that is never -0.0)
+                    if (lane < MC) {
+                        tl[j * MC + lane] = t0;
+                        if (two) tl[(j + 1) * MC + lane] = t1;
+                    }
+                }
+                cached = true;
+                cnt = n;
+                ordv = lane;
+                used = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+                wave_sync();
+            } else {  // more columns at a nonzero bound than the cache holds: lane by lane, every pass
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    unsigned long long m = mc[c];
+                    while (m) {  // uniform
+                        const int l = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const double xk = xL[l + 64 * c];
+                        double y = 0.0;
+#pragma unroll
+                        for (int t = 0; t < MC; ++t) y += ivr[t] * readlane_f64(a[c][t], l);
+                        a2 += y * xk;
+                    }
+                }
+                cached = false;
+                cnt = 0;
+            }
+            rebuild = false;
+        } else {  // the cached terms, re-added in ascending order of their columns, eight LDS reads per round trip
+            for (int p0 = 0; p0 < cnt; p0 += 8) {
+                double tv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int slot = __builtin_amdgcn_readlane(ordv, (p0 + q) & 63);
+                    tv[q] = tl[slot * MC + (lane < MC ? lane : 0)];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a2 += (p0 + q < cnt) ? tv[q] : 0.0;   // (+0.0 on a sum that is never -0.0)
             }
         }
         double s = 0.0;
 #pragma unroll
-        for (int t = 0; t < MC; ++t)
-            if (t < M0) s += ivr[t] * readlane_f64(rhs, t);
+        for (int t = 0; t < MC; ++t) s += ivr[t] * readlane_f64(rhs, t);
         xb = s - a2;
+        W1_STAMP(7);  // xb
     }
+    W1_FLUSH();
 
     // ---- finish(): values of the basic variables; then initQP's mapping back (SSQP.jl:531-559)
-    if (status >= 0) {
-        for (int j = 0; j < M0; ++j) col_set<NC>(xv, __builtin_amdgcn_readlane(bas, j), readlane_f64(xb, j));
-    }
+    wave_sync();
+    if (status >= 0 && lane < M0) xL[bas] = xb;
+    wave_sync();
     int feasible = 1;
     if (status >= 0) {
         double art = 0.0;
-        for (int kk = N0; kk < N1; ++kk) art += col_get<NC>(xv, kk);
+        for (int kk = N0; kk < N1; ++kk) art += xL[kk];
         feasible = (art > tol) ? 0 : 1;
     }
     const bool mapBack = status >= 0 && feasible == 1;
@@ -504,7 +672,7 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
         const int k = lane + 64 * c;
         const int sk = (int)((stw >> (2 * c)) & 3u);
         if (k < N) {
-            double xk = xv[c];
+            double xk = xL[k];
             if (mapBack && ((upw >> c) & 1u)) xk = -xk;   // (statuses stay: SSQP.jl:552-557 is a no-op)
             x0[k] = xk;
             S[k] = sk;

@@ -45,8 +45,23 @@ hipError_t launch_phase1_wave(int nprob, int N, int M, int J, const double *A, c
     P.fbCount = fbCount; P.fbList = fbList;
     const int M0 = M + J, N1 = N + J + M0;
     // builds by column slots (64 columns each) and rows: the loops over both are unrolled over register arrays
-    if (N1 <= 64 * 5) return M0 <= 4 ? launch<5, 4>(P, stream) : launch<5, 11>(P, stream);
-    return M0 <= 4 ? launch<9, 4>(P, stream) : launch<9, 11>(P, stream);
+    if (N1 <= 64 * 5) return M0 <= 4 ? launch<5, 4>(P, stream) : (M0 <= 8 ? launch<5, 8>(P, stream) : launch<5, 11>(P, stream));
+    return M0 <= 4 ? launch<9, 4>(P, stream) : (M0 <= 8 ? launch<9, 8>(P, stream) : launch<9, 11>(P, stream));
 }
 
+#ifdef SSQP_PHASE_PROFILE
+int phase1_wave_debug_phases(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(p1w::g_p1wphase), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        static unsigned long long zero[16];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(p1w::g_p1wphase), zero, sizeof(zero)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
+
 }  // namespace ssqp
+
+#ifdef SSQP_PHASE_PROFILE
+extern "C" int ssqp_debug_phase1_wave_phases(unsigned long long *out16, int reset) { return ssqp::phase1_wave_debug_phases(out16, reset); }
+#endif

@@ -14,6 +14,7 @@ db, prob, x0, S0 = pkg.DeviceBatch.generated(cfg, nprob)
 lib = pkg._capi.lib()
 lib.ssqp_debug_phase1_phases.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 out = (C.c_ulonglong * 16)()
+db.ctx.set_option("phase1_wave", 0)
 db.phase1(); db.torch.cuda.synchronize()
 lib.ssqp_debug_phase1_phases(out, 1)
 db.phase1(); db.torch.cuda.synchronize()
@@ -26,3 +27,19 @@ print("config", name, "nprob", nprob, "simplex passes per QP %.1f, basis changes
     it / nprob, bc / nprob, tot / nprob))
 for i, n in enumerate(names):
     print("%-34s %6.2f %%  %9.0f cycles per QP" % (n, 100.0 * out[i] / tot, out[i] / nprob))
+
+# ---- the one-wavefront-per-QP kernel (the default where it applies): its own stamps
+lib.ssqp_debug_phase1_wave_phases.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+db.ctx.set_option("phase1_wave", 1)
+db.phase1(); db.torch.cuda.synchronize()
+lib.ssqp_debug_phase1_wave_phases(out, 1)
+db.phase1(); db.torch.cuda.synchronize()
+lib.ssqp_debug_phase1_wave_phases(out, 1)
+wn = ["set-up (LP columns into registers, first Y.c)", "pricing + first maximum", "entering column + ratio test",
+      "basis sort + columns", "inv(lu(B)) in registers", "rows of the inverse, statuses", "Y.c refresh", "xb = invB b - Y x"]
+tot = sum(out[:8])
+if tot:
+    print("wavefront kernel: simplex passes per QP %.1f, basis changes per QP %.1f, cycles per QP %.0f" % (
+        out[14] / nprob, out[15] / nprob, tot / nprob))
+    for i, n in enumerate(wn):
+        print("%-46s %6.2f %%  %9.0f cycles per QP" % (n, 100.0 * out[i] / tot, out[i] / nprob))
