@@ -228,6 +228,21 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *ctx, int nprob, int N, int M, int
                                      const double *dx0, double *dz, const ssqp_settings *settings,
                                      int64_t *dstatus, int32_t *ddetail, ssqp_stats *dstats,
                                      ssqp_trace *dtrace, int ntrace, double *dlambda, double *dgamma, void *stream);
+/* solveQP(Q::QP; settings, settingsLP) for a batch resident in HBM, BOTH stages in ONE kernel launch per QP
+ * (replaces SSQP.jl:224-234 = initQP, :229, + the loop, :233): the wavefront that finds a QP's Phase-1 vertex goes straight on
+ * into the active-set loop for it -- no (x0, S0) round trip, no second launch.  dS and dz are outputs only.  Per QP the
+ * result is the reference's triple: status > 0 (passes) with (z, S) of the loop, or Phase-1's verdict (0 infeasible, -1
+ * singular basis with detail SSQP_DETAIL_SINGULAR_LU) with z = x0 and Phase-1's S, as SSQP.jl:230-232 returns them.
+ * settingsLP NULL = settings (the reference's default).  The model check `Q.mc <= 0` (SSQP.jl:226-228) belongs to the QP
+ * constructor and stays with the caller.  Shapes: per-problem arrays, N even <= 512, 1 <= M + J <= 11,
+ * N + J + M + J <= 576, default algorithm options (SSQP_ERR_UNSUPPORTED otherwise: call ssqp_phase1_batch_dev_f64 and
+ * ssqp_solve_batch_dev_f64).  QPs with free variables take the workgroup Phase-1 kernel behind the same call.
+ * Asynchronous on `stream`; lambda / gamma / stats as for ssqp_solve_batch_dev_f64. */
+int ssqp_solve_full_batch_dev_f64(ssqp_ctx *ctx, int nprob, int N, int M, int J, const double *dV, const double *dA,
+                                  const double *dG, const double *dq, const double *db, const double *dg,
+                                  const double *dd, const double *du, int32_t *dS, double *dz,
+                                  const ssqp_settings *settings, const ssqp_settings *settingsLP, int64_t *dstatus,
+                                  int32_t *ddetail, ssqp_stats *dstats, double *dlambda, double *dgamma, void *stream);
 /* "lazy_handover" only: issues the launch the last call on ctx may still owe (waits for that call's wavefront kernel,
  * not for the stream).  A host that reuses the call's in/out buffers (S is in/out) must flush BEFORE it queues work
  * that overwrites them. */

@@ -81,6 +81,8 @@ SIGNATURES = {
     "ssqp_recent_kernel_ms": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float)]),
     "ssqp_phase1_f64": (C.c_int, [C.c_int] * 3 + [_vp] * 6 + [C.POINTER(CSettings), _vp, _vp, _ip]),
     "ssqp_phase1_batch_f64": (C.c_int, [C.c_int] * 4 + [_vp] * 6 + [C.POINTER(CSettings), _vp, _vp, _vp, C.c_int]),
+    "ssqp_solve_full_batch_dev_f64": (C.c_int, [_vp] + [C.c_int] * 4 + [_vp] * 8 + [_vp, _vp, C.POINTER(CSettings),
+                                                 C.POINTER(CSettings), _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssqp_phase1_batch_dev_f64": (C.c_int, [_vp] + [C.c_int] * 4 + [_vp] * 6 + [C.POINTER(CSettings), _vp, _vp, _vp, _vp]),
     "ssqp_generate_problem": (C.c_int, [C.POINTER(CGenCfg), C.c_uint64] + [_vp] * 8),
     "ssqp_generate_batch": (C.c_int, [C.POINTER(CGenCfg), C.c_uint64, C.c_int] + [_vp] * 8 + [C.c_int]),

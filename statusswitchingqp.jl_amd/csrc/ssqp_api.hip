@@ -40,7 +40,7 @@ struct ssqp_ctx {
     const void *pinnedPtr = nullptr;
     size_t pinnedBytes = 0;
     // grow-only device workspaces
-    DevBuf Ct, rhs, queue, gscratch, fbList, fbList2, fbIter, wscratch, wscratchBig, p1ws, p1wsInt, p1queue, p1list;
+    DevBuf Ct, rhs, queue, gscratch, fbList, fbList2, fbIter, wscratch, wscratchBig, p1ws, p1wsInt, p1queue, p1list, fullX0, fullSt;
     int optPhase1Wave = 1;   // 0: Phase-1 by the workgroup kernel only
     // staging buffers of the host-pointer entry points
     DevBuf hV, hA, hG, hq, hb, hg, hd, hu, hS, hx0, hz, hstatus, hdetail, hstats, hlam, hgam;
@@ -155,7 +155,7 @@ int ssqp_ctx_destroy(ssqp_ctx *c) {
     c->lanes.clear();
     for (hipEvent_t &e : c->evCopy)
         if (e) (void)hipEventDestroy(e), e = nullptr;
-    for (DevBuf *b : {&c->Ct, &c->rhs, &c->queue, &c->gscratch, &c->fbList, &c->fbList2, &c->fbIter, &c->wscratch, &c->wscratchBig, &c->p1ws, &c->p1wsInt, &c->p1queue, &c->p1list, &c->hV, &c->hA, &c->hG, &c->hq, &c->hb, &c->hg,
+    for (DevBuf *b : {&c->Ct, &c->rhs, &c->queue, &c->gscratch, &c->fbList, &c->fbList2, &c->fbIter, &c->wscratch, &c->wscratchBig, &c->p1ws, &c->p1wsInt, &c->p1queue, &c->p1list, &c->fullX0, &c->fullSt, &c->hV, &c->hA, &c->hG, &c->hq, &c->hb, &c->hg,
                       &c->hd, &c->hu, &c->hS, &c->hx0, &c->hz, &c->hstatus, &c->hdetail, &c->hstats, &c->hlam, &c->hgam})
         release(*b);
     for (int k = 0; k < ssqp_ctx::EV_RING; ++k) {
@@ -283,18 +283,23 @@ int ssqp_recent_kernel_ms(ssqp_ctx *c, int back, float *ms) {
 
 int ssqp_last_kernel_ms(ssqp_ctx *c, float *ms) { return ssqp_recent_kernel_ms(c, 0, ms); }
 
-int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const double *dV, const double *dA,
-                                     const double *dG, const double *dq, const double *db, const double *dg,
-                                     const double *dd, const double *du, const ssqp_batch_strides *strides,
-                                     int32_t *dS, const double *dx0, double *dz, const ssqp_settings *settings,
-                                     int64_t *dstatus, int32_t *ddetail, ssqp_stats *dstats, ssqp_trace *dtrace,
-                                     int ntrace, double *dlambda, double *dgamma, void *stream) {
+}  // extern "C"
+
+// the device-buffer solve; `settingsLP` non-null = solveQP(Q) in one launch: Phase-1 runs in front of the loop inside the
+// first stage's kernel (dx0 is then null: the vertex lives in a workspace of the context)
+static int solve_dev_impl(ssqp_ctx *c, int nprob, int N, int M, int J, const double *dV, const double *dA,
+                          const double *dG, const double *dq, const double *db, const double *dg,
+                          const double *dd, const double *du, const ssqp_batch_strides *strides,
+                          int32_t *dS, const double *dx0, double *dz, const ssqp_settings *settings,
+                          int64_t *dstatus, int32_t *ddetail, ssqp_stats *dstats, ssqp_trace *dtrace,
+                          int ntrace, double *dlambda, double *dgamma, void *stream, const ssqp_settings *settingsLP) {
+    const bool full = settingsLP != nullptr;
     ssqp_batch_strides st0;
     st0.V = (size_t)N * N; st0.A = (size_t)M * N; st0.G = (size_t)J * N; st0.q = N; st0.b = M; st0.g = J; st0.d = N; st0.u = N;
     const ssqp_batch_strides *sd = strides ? strides : &st0;
     int rc = check_dims(c, nprob, N, M, J);
     if (rc != SSQP_OK) return rc;
-    if (!dV || !dq || !dd || !du || !dS || !dx0 || !dz || !dstatus || (M > 0 && (!dA || !db)) ||
+    if (!dV || !dq || !dd || !du || !dS || (!dx0 && !full) || !dz || !dstatus || (M > 0 && (!dA || !db)) ||
         (J > 0 && (!dG || !dg))) {
         c->err = "null pointer";
         return SSQP_ERR_ARG;
@@ -303,6 +308,20 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
     ssqp_settings def;
     ssqp_default_settings(&def);
     const ssqp_settings *st = settings ? settings : &def;
+    if (full) {
+        if (settingsLP->rule != 0) {
+            c->err = "only rule = :Dantzig is implemented for Phase-1";
+            return SSQP_ERR_UNSUPPORTED;
+        }
+        const bool packed = sd->A == (size_t)M * N && sd->G == (size_t)J * N && sd->b == (size_t)M && sd->g == (size_t)J &&
+                            sd->d == (size_t)N && sd->u == (size_t)N;
+        if (!packed || !ssqp::phase1_wave_applies(N, M, J) || !ssqp::wave_kernel_applies(N, M, J) || !c->optWaveKernel ||
+            c->optWaveKernel == 2 || !c->optIncremental || c->optDenseGamma || !c->optPhase1Wave) {
+            c->err = "single-launch solveQP(Q) takes per-problem A, G, b, g, d, u with N even <= 512, 1 <= M + J <= 11, "
+                     "N + J + M + J <= 576, default options: use ssqp_phase1_batch_dev_f64 + ssqp_solve_batch_dev_f64";
+            return SSQP_ERR_UNSUPPORTED;
+        }
+    }
     if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return SSQP_ERR_HIP;
     hipStream_t s = (hipStream_t)stream;  // NULL is HIP's default stream (what torch uses unless told otherwise)
     {
@@ -348,7 +367,8 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
         // global scratch) hides each wavefront's waits behind another one: the better choice when more QPs are in flight
         // than 4 per CU -- a batch above 4 * numCU QPs, or several contexts busy on different streams (the caller says
         // so with the option)
-        const int qpc = c->optWaveQPC > 0 ? c->optWaveQPC : (nprob > 4 * c->numCU ? 8 : 4);
+        // (the single-launch solveQP(Q) is the four-per-CU build: Phase-1 keeps the LP's columns in 512 registers)
+        const int qpc = full ? 4 : (c->optWaveQPC > 0 ? c->optWaveQPC : (nprob > 4 * c->numCU ? 8 : 4));
         if (qpc > 4) {  // two wavefronts per SIMD: 256 registers, rows >= 64 of the factor in global scratch
             waveWps = 2;
             waveRC = N < 127 ? N : 127;
@@ -372,6 +392,12 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
     if (!ensure(c, c->Ct, (size_t)nprob * MJ * N * 8) || !ensure(c, c->rhs, (size_t)nprob * MJ * 8) ||
         !ensure(c, c->queue, 64) || !ensure(c, c->gscratch, (size_t)grid * gstride * 8))
         return SSQP_ERR_ALLOC;
+    if (full && (!ensure(c, c->fullX0, (size_t)nprob * N * 8) || !ensure(c, c->fullSt, (size_t)nprob * 4) ||
+                 !ensure(c, c->p1queue, 64) || !ensure(c, c->p1list, (size_t)nprob * 4) ||
+                 !ensure(c, c->p1ws, (size_t)nprob * ssqp::phase1_ws_doubles(N, M, J) * 8) ||
+                 !ensure(c, c->p1wsInt, (size_t)nprob * ssqp::phase1_ws_ints(N, M, J) * 4)))
+        return SSQP_ERR_ALLOC;
+    if (full) dx0 = (const double *)c->fullX0.p;
     if (useWave && (!ensure(c, c->fbList, (size_t)nprob * 4) || !ensure(c, c->fbList2, (size_t)nprob * 4) ||
                     !ensure(c, c->fbIter, (size_t)nprob * 8) || !ensure(c, c->wscratch, (size_t)waveGrid * wstride * 8) ||
                     (bigStage && !ensure(c, c->wscratchBig, (size_t)bigGrid * wstrideBig * 8))))
@@ -421,6 +447,7 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
     }
 
     if (!hip_ok(c, hipMemsetAsync(c->queue.p, 0, 64, s), "hipMemsetAsync")) return SSQP_ERR_HIP;
+    if (full && !hip_ok(c, hipMemsetAsync(c->p1queue.p, 0, 64, s), "hipMemsetAsync")) return SSQP_ERR_HIP;
     ssqp::launch_prep(sharedC ? 1 : nprob, sharedR ? 1 : nprob, N, M, J, dA, dG, db, dg, sd->A, sd->G, sd->b, sd->g,
                       (double *)c->Ct.p, (double *)c->rhs.p, s);
     if (!hip_ok(c, hipGetLastError(), "prep launch")) return SSQP_ERR_HIP;
@@ -448,7 +475,19 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
             W.fbCount = qw + 3;
             W.fbList = (int *)c->fbList2.p;
         }
-        if (bigFirst) {
+        if (full) {
+            // Phase-1 + loop in one kernel; what its Phase-1 does not take (free variables) goes through the workgroup
+            // Phase-1 kernel, which appends the feasible ones to the first stage's hand-over list at pass 0
+            if (!hip_ok(c, ssqp::launch_solve_full(P, waveGrid, dA, dG, db, dg, settingsLP->tol, (double *)c->fullX0.p,
+                                                   (int32_t *)c->fullSt.p, (unsigned int *)c->p1queue.p, (int *)c->p1list.p, s),
+                        "single-launch solve")) return SSQP_ERR_HIP;
+            ssqp::Phase1Handover ho{P.fbCount, P.fbList, P.fbIter, dz, dstatus, ddetail, dstats};
+            if (!hip_ok(c, ssqp::launch_phase1(nprob, N, M, J, dA, dG, db, dg, dd, du, settingsLP->tol, (double *)c->fullX0.p, dS,
+                                               (int32_t *)c->fullSt.p, (double *)c->p1ws.p, ssqp::phase1_ws_doubles(N, M, J),
+                                               (int *)c->p1wsInt.p, ssqp::phase1_ws_ints(N, M, J),
+                                               (const unsigned int *)c->p1queue.p, (const int *)c->p1list.p, 2 * c->numCU, &ho, s),
+                        "phase-1 launch")) return SSQP_ERR_HIP;
+        } else if (bigFirst) {
             if (!hip_ok(c, ssqp::launch_solve_wave(B, bigGrid, 2, s), "big-factor wave launch")) return SSQP_ERR_HIP;
         } else {
             if (!hip_ok(c, ssqp::launch_solve_wave(P, waveGrid, waveWps == 2 ? 1 : 0, s), "wave solve launch")) return SSQP_ERR_HIP;
@@ -484,6 +523,30 @@ int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J
     if (!hip_ok(c, ssqp::launch_solve(P, grid, (size_t)lay.total_bytes, wgPerCU, s), "solve launch")) return SSQP_ERR_HIP;
     if (!hip_ok(c, hipEventRecord(c->evE[slot], s), "hipEventRecord")) return SSQP_ERR_HIP;
     return SSQP_OK;
+}
+
+extern "C" {
+
+int ssqp_solve_batch_strided_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const double *dV, const double *dA,
+                                     const double *dG, const double *dq, const double *db, const double *dg,
+                                     const double *dd, const double *du, const ssqp_batch_strides *strides,
+                                     int32_t *dS, const double *dx0, double *dz, const ssqp_settings *settings,
+                                     int64_t *dstatus, int32_t *ddetail, ssqp_stats *dstats, ssqp_trace *dtrace,
+                                     int ntrace, double *dlambda, double *dgamma, void *stream) {
+    return solve_dev_impl(c, nprob, N, M, J, dV, dA, dG, dq, db, dg, dd, du, strides, dS, dx0, dz, settings, dstatus, ddetail,
+                          dstats, dtrace, ntrace, dlambda, dgamma, stream, nullptr);
+}
+
+int ssqp_solve_full_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const double *dV, const double *dA,
+                                  const double *dG, const double *dq, const double *db, const double *dg,
+                                  const double *dd, const double *du, int32_t *dS, double *dz,
+                                  const ssqp_settings *settings, const ssqp_settings *settingsLP, int64_t *dstatus,
+                                  int32_t *ddetail, ssqp_stats *dstats, double *dlambda, double *dgamma, void *stream) {
+    ssqp_settings def;
+    ssqp_default_settings(&def);
+    const ssqp_settings *lp = settingsLP ? settingsLP : (settings ? settings : &def);   // settingsLP = settings (SSQP.jl:224)
+    return solve_dev_impl(c, nprob, N, M, J, dV, dA, dG, dq, db, dg, dd, du, nullptr, dS, nullptr, dz, settings, dstatus, ddetail,
+                          dstats, nullptr, 0, dlambda, dgamma, stream, lp);
 }
 
 int ssqp_solve_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const double *dV, const double *dA,
@@ -764,7 +827,7 @@ int ssqp_phase1_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const
     // (the workspaces are indexed by problem id: a listed QP may be any of them)
     if (!ensure(c, c->p1ws, (size_t)nprob * wd * 8) || !ensure(c, c->p1wsInt, (size_t)nprob * wi * 4)) return SSQP_ERR_ALLOC;
     return hip_ok(c, ssqp::launch_phase1(nprob, N, M, J, dA, dG, db, dg, dd, du, st->tol, dx0, dS, dstatus,
-                                         (double *)c->p1ws.p, wd, (int *)c->p1wsInt.p, wi, listCount, list, 2 * c->numCU, s),
+                                         (double *)c->p1ws.p, wd, (int *)c->p1wsInt.p, wi, listCount, list, 2 * c->numCU, nullptr, s),
                   "phase-1 launch") ? SSQP_OK : SSQP_ERR_HIP;
 }
 

@@ -176,16 +176,31 @@ hipError_t launch_solve_wave(const SolveParams &P, int grid, int variant, hipStr
 size_t phase1_ws_doubles(int N, int M, int J);
 size_t phase1_ws_ints(int N, int M, int J);
 size_t phase1_lds_bytes(int M, int J);
+// single-launch solveQP(Q): where the workgroup Phase-1 kernel sends a QP of its list on into the loop (a hand-over at pass 0)
+struct Phase1Handover {
+    unsigned int *count;
+    int *list;
+    long long *iter;
+    double *z;
+    int64_t *status;
+    int32_t *detail;
+    ssqp_stats *stats;
+};
 hipError_t launch_phase1(int nprob, int N, int M, int J, const double *A, const double *G, const double *b, const double *g,
                          const double *d, const double *u, double tol, double *x0, int32_t *S, int32_t *status, double *ws,
                          size_t wsStride, int *wsInt, size_t wsIntStride, const unsigned int *listCount, const int *list, int gridCap,
-                         hipStream_t stream);
+                         const Phase1Handover *ho, hipStream_t stream);
 // ---- Phase-1, one wavefront per QP (ssqp_phase1_wave.hip): M + J <= 11 rows and N + J + M + J <= 576 columns; a QP with a
 // free variable is left on (fbCount, fbList) for the workgroup kernel
 bool phase1_wave_applies(int N, int M, int J);
 hipError_t launch_phase1_wave(int nprob, int N, int M, int J, const double *A, const double *G, const double *b, const double *g,
                               const double *d, const double *u, double tol, double *x0, int32_t *S, int32_t *status,
                               unsigned int *fbCount, int *fbList, hipStream_t stream);
+
+// ---- solveQP(Q) in one launch (ssqp_wave.hip built with -DSSQP_FULL): the wavefront Phase-1 in front of the four-per-CU
+// build of the loop; P as for launch_solve_wave(variant 0), x0 = the vertex buffer (P.x0 must point to it too)
+hipError_t launch_solve_full(const SolveParams &P, int grid, const double *A, const double *G, const double *b, const double *g,
+                             double tolLP, double *x0, int32_t *p1status, unsigned int *p1Count, int *p1List, hipStream_t stream);
 
 }  // namespace ssqp
 #endif

@@ -319,6 +319,16 @@ struct P1Params {
     // the QPs the one-wavefront-per-QP kernel (ssqp_phase1_wave.hip) did not take: problem ids and their count (null: all)
     const unsigned int *listCount;
     const int *list;
+    // single-launch solveQP(Q) (ssqp_solve_full_batch_dev_f64): a QP of the list goes on into the loop as a hand-over at pass
+    // 0 -- z = x0, fbIter = 0, zeroed statistics, its id appended to (hoCount, hoList) -- when its vertex is feasible, and
+    // ends here with (x0, S, status) otherwise (SSQP.jl:229-232).  hoList null: plain Phase-1.
+    unsigned int *hoCount;
+    int *hoList;
+    long long *hoIter;
+    double *z;
+    int64_t *status64;
+    int32_t *detail;
+    ssqp_stats *stats;
 };
 
 __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob, unsigned char *smem) {
@@ -839,8 +849,23 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
     for (int k = tid; k < N; k += NT1) x0[k] = x[k];
     for (int k = tid; k < N + J; k += NT1) S[k] = S1[k];
     __syncthreads();
+    auto endHere = [&](int st) {  // (single-launch solveQP(Q): the QP ends with Phase-1's verdict)
+        if (!P.hoList) return;
+        double *z = P.z + (size_t)prob * N;
+        for (int k = tid; k < N; k += NT1) z[k] = x[k];
+        if (tid == 0) {
+            P.status64[prob] = st;
+            if (P.detail) P.detail[prob] = st < 0 ? SSQP_DETAIL_SINGULAR_LU : SSQP_DETAIL_NONE;
+        }
+    };
+    if (P.hoList && P.stats && tid == 0) {
+        ssqp_stats z0;
+        z0.iters = 0; z0.alg_bytes = 0; z0.read_bytes = 0; z0.alg_flops = 0; z0.sum_k3 = 0; z0.max_k = 0; z0.path = 128;
+        P.stats[prob] = z0;
+    }
     if (status < 0) {
         if (tid == 0) P.status[prob] = -1;
+        endHere(-1);
         return;
     }
     if (tid == 0) {
@@ -850,7 +875,10 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
         P.status[prob] = misc[0];
     }
     __syncthreads();
-    if (misc[0] == 0) return;
+    if (misc[0] == 0) {
+        endHere(0);
+        return;
+    }
     for (int k = N + tid; k < N + J; k += NT1) S[k] = (S1[k] == SSQP_IN) ? SSQP_OE : SSQP_EO;
     for (int t = tid; t < nfree; t += NT1) {
         x0[freeVars[t]] = x[freeVars[t]] - x[N + J + t];
@@ -858,6 +886,16 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
     }
     __syncthreads();
     for (int t = tid; t < nup; t += NT1) x0[upperOnly[t]] = -x0[upperOnly[t]];  // (statuses stay: SSQP.jl:552-557 is a no-op)
+    if (P.hoList) {  // on into the loop: a hand-over at pass 0
+        __syncthreads();
+        double *z = P.z + (size_t)prob * N;
+        for (int k = tid; k < N; k += NT1) z[k] = x0[k];
+        if (tid == 0) {
+            P.hoIter[prob] = 0;
+            const unsigned slot = atomicAdd(P.hoCount, 1u);
+            P.hoList[slot] = prob;
+        }
+    }
 }
 
 __global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (four workgroups per CU: 1,024 QPs resident)
@@ -892,9 +930,12 @@ static size_t phase1_lds_bytes_vec(int N, int M, int J) {
 hipError_t launch_phase1(int nprob, int N, int M, int J, const double *A, const double *G, const double *b, const double *g,
                          const double *d, const double *u, double tol, double *x0, int32_t *S, int32_t *status, double *ws,
                          size_t wsStride, int *wsInt, size_t wsIntStride, const unsigned int *listCount, const int *list, int gridCap,
-                         hipStream_t stream) {
+                         const Phase1Handover *ho, hipStream_t stream) {
     p1::P1Params P;
     P.listCount = listCount; P.list = list;
+    P.hoCount = ho ? ho->count : nullptr; P.hoList = ho ? ho->list : nullptr; P.hoIter = ho ? ho->iter : nullptr;
+    P.z = ho ? ho->z : nullptr; P.status64 = ho ? ho->status : nullptr; P.detail = ho ? ho->detail : nullptr;
+    P.stats = ho ? ho->stats : nullptr;
     P.nprob = nprob; P.N = N; P.M = M; P.J = J;
     P.A = A; P.G = G; P.b = b; P.g = g; P.d = d; P.u = u;
     P.tol = tol;

@@ -180,7 +180,7 @@ __device__ __forceinline__ bool invert_lu_regs(double (&col)[MC], int n) {
 }
 
 // One QP.  `lds`: lds_doubles<NC, MC>() doubles of this wavefront's LDS.  Returns false when the QP was not taken (it has
-// free variables and now sits on P.fbList); otherwise x0, S and status are written.
+// free variables and now sits on P.fbList); otherwise x0, S and status are written (statusOut: the same status, uniform).
 // Padding: rows M0 .. MC - 1 of every column, of inv(B) and of the row vectors are exactly +0.0, so the loops over rows
 // carry no guard on M0: a padded row adds 0.0 * 0.0 = +0.0 to a sum that started at +0.0 and therefore is never -0.0 (x + y
 // = -0.0 needs x = y = -0.0) -- no bit of any sum changes.
@@ -189,8 +189,9 @@ constexpr int TCAP = 64;
 #define RGBIG 1
 #endif   // nonbasic columns at a nonzero value whose xb terms are cached (more: recomputed every pass)
 template <int NC, int MC>
-__device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds) {
+__device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds, int &statusOut) {
 #pragma clang fp contract(off)
+    statusOut = -2;
     const int lane = threadIdx.x & 63;
     W1_DECL;
     const int N = P.N, M = P.M, J = P.J, M0 = M + J;
@@ -325,6 +326,7 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
     // an entry of the LP (half of them live in the accumulator half of the register file) is fetched once per group.
     constexpr int RG = (NC * MC > 60) ? RGBIG : 3;   // rows per round (the accumulators of a round: RG x NC doubles)
     auto refreshY = [&]() __attribute__((always_inline)) {
+#pragma clang fp contract(off)
 #pragma unroll
         for (int c = 0; c < NC; ++c) sd[c] = 0.0;
         unsigned long long rows = __ballot(lane < M0 && bas >= N0);
@@ -680,7 +682,8 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
             S[k] = mapBack ? ((sk == SSQP_IN) ? SSQP_OE : SSQP_EO) : sk;
         }
     }
-    if (lane == 0) P.status[prob] = status < 0 ? -1 : feasible;
+    statusOut = status < 0 ? -1 : feasible;
+    if (lane == 0) P.status[prob] = statusOut;
     wave_sync();
     return true;
 }

@@ -18,7 +18,8 @@ __global__ __launch_bounds__(64, 1) void ssqp_phase1_wave_kernel(p1w::Params P) 
     __shared__ __attribute__((aligned(16))) double lds[p1w::lds_doubles<NC, MC>()];
     const int prob = blockIdx.x;
     if (prob >= P.nprob) return;
-    (void)p1w::solve_one<NC, MC>(P, prob, lds);
+    int st;
+    (void)p1w::solve_one<NC, MC>(P, prob, lds, st);
 }
 
 template <int NC, int MC>

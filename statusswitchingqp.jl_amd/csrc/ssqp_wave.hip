@@ -27,6 +27,9 @@
 #include "ssqp_hip.h"
 #include "ssqp_internal.h"
 #include "ssqp_device.h"
+#ifdef SSQP_FULL
+#include "ssqp_phase1_wave.h"   // (the single-launch solveQP(Q): Phase-1 in front of the loop, SSQP_WAVE_VARIANT 0 only)
+#endif
 
 namespace ssqp {
 
@@ -2857,54 +2860,60 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
 //                  substitution), every stream through an LDS ring filled by LDS-DMA loads.  It takes the QPs builds
 //                  0 / 1 hand over (P.resume: problem ids from their hand-over list, start from the (z, S) they left).
 // Each hands a QP that outgrows it over to the next stage (0 / 1 -> 2 -> the workgroup kernel).
+// the carve-up of a wavefront's LDS and global scratch (every build)
+template <bool PARK>
+__device__ __forceinline__ void wave_carve(const SolveParams &P, unsigned char *smem, WLds &L, double *&gscr, double *&park) {
+    gscr = P.wscratch + (size_t)blockIdx.x * P.wscratchStride;
+    park = gscr;
+    double *d0 = reinterpret_cast<double *>(smem);
+    const int rc = P.waveRC;
+    int o = 0;
+    L.F.L0 = d0 + o; o += 2080;
+    L.F.LR = nullptr;
+    if (NSL > 2) {  // least-squares scratch for up to 256 rows, then rows 64..255 of up to 256 columns
+        L.F.L1 = gscr + WAVE_LS_DOUBLES_BIG;
+        L.F.R1 = 192;
+        L.F.LR = gscr + WAVE_LS_DOUBLES_BIG + 256 * 192 + 64;
+    } else if (PARK) {
+        L.F.L1 = gscr + WAVE_LS_DOUBLES;
+        L.F.R1 = 64;
+        park = gscr + WAVE_LS_DOUBLES + 128 * 64;
+    } else {
+        const int r1 = rc > 64 ? rc - 64 : 0;
+        L.F.L1 = d0 + o; o += rc * r1 + 2;
+        L.F.R1 = r1 > 0 ? r1 : 1;
+    }
+    L.H = d0 + o; o += NR * NR;
+    L.tr = d0 + o; o += MJX * MJX + 1;
+    L.aLrow = d0 + o; o += 16;
+    L.yn = d0 + o; o += 16;
+    L.GG = d0 + o; o += MJX * MJX + 1;
+    L.xn = d0 + o; o += 16;
+    L.ra = reinterpret_cast<int16_t *>(d0 + o);
+    o += 8;
+    L.ring = nullptr;
+    L.ringAddr = 0u;
+    L.zidx = o;                     // (a double that stays zero: what a masked-out lane of a gather or of the factor sweeps reads)
+    L.zero = d0 + o;
+    if (threadIdx.x == 0) d0[o] = 0.0;
+    o += 2;
+    if (NSL > 2) {
+        o = (o + 127) / 128 * 128;  // (1 KiB alignment of the DMA pieces)
+        L.ring = d0 + o;
+        // low half of the flat address of an LDS location = its LDS byte address; read through v_readfirstlane so that
+        // the compiler keeps ONE scalar instead of re-deriving it (with its null-pointer select) at every DMA
+        L.ringAddr = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(d0 + o));
+    }
+}
+
+#ifndef SSQP_FULL
 template <int WPS, bool PARK, int SLOTS>  // (SLOTS = NSL: part of the kernel's name, so that the builds' kernels differ)
 __global__ __launch_bounds__(64, WPS) void ssqp_wave_kernel(SolveParams P) {
     static_assert(SLOTS == NSL, "one build per translation unit");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WLds L;
-    double *gscr = P.wscratch + (size_t)blockIdx.x * P.wscratchStride;
-    double *park = gscr;
-    {
-        double *d0 = reinterpret_cast<double *>(smem);
-        const int rc = P.waveRC;
-        int o = 0;
-        L.F.L0 = d0 + o; o += 2080;
-        L.F.LR = nullptr;
-        if (NSL > 2) {  // least-squares scratch for up to 256 rows, then rows 64..255 of up to 256 columns
-            L.F.L1 = gscr + WAVE_LS_DOUBLES_BIG;
-            L.F.R1 = 192;
-            L.F.LR = gscr + WAVE_LS_DOUBLES_BIG + 256 * 192 + 64;
-        } else if (PARK) {
-            L.F.L1 = gscr + WAVE_LS_DOUBLES;
-            L.F.R1 = 64;
-            park = gscr + WAVE_LS_DOUBLES + 128 * 64;
-        } else {
-            const int r1 = rc > 64 ? rc - 64 : 0;
-            L.F.L1 = d0 + o; o += rc * r1 + 2;
-            L.F.R1 = r1 > 0 ? r1 : 1;
-        }
-        L.H = d0 + o; o += NR * NR;
-        L.tr = d0 + o; o += MJX * MJX + 1;
-        L.aLrow = d0 + o; o += 16;
-        L.yn = d0 + o; o += 16;
-        L.GG = d0 + o; o += MJX * MJX + 1;
-        L.xn = d0 + o; o += 16;
-        L.ra = reinterpret_cast<int16_t *>(d0 + o);
-        o += 8;
-        L.ring = nullptr;
-        L.ringAddr = 0u;
-        L.zidx = o;                     // (a double that stays zero: what a masked-out lane of a gather or of the factor sweeps reads)
-        L.zero = d0 + o;
-        if (threadIdx.x == 0) d0[o] = 0.0;
-        o += 2;
-        if (NSL > 2) {
-            o = (o + 127) / 128 * 128;  // (1 KiB alignment of the DMA pieces)
-            L.ring = d0 + o;
-            // low half of the flat address of an LDS location = its LDS byte address; read through v_readfirstlane so that
-            // the compiler keeps ONE scalar instead of re-deriving it (with its null-pointer select) at every DMA
-            L.ringAddr = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(d0 + o));
-        }
-    }
+    double *gscr, *park;
+    wave_carve<PARK>(P, smem, L, gscr, park);
     for (;;) {
         int prob = 0;
         if (threadIdx.x == 0) prob = (int)atomicAdd(P.queue, 1u);
@@ -2918,9 +2927,122 @@ __global__ __launch_bounds__(64, WPS) void ssqp_wave_kernel(SolveParams P) {
         wave_solve_one<PARK>(P, prob, L, gscr, park);
     }
 }
+#else
+// ---- solveQP(Q) in ONE launch (SSQP.jl:224-234): the wavefront that finds a QP's Phase-1 vertex (ssqp_phase1_wave.h: initQP +
+// cDantzigLP, one wavefront per QP) goes straight on into the loop for that QP -- no second launch, no launch tail
+// between the stages, the vertex (x0, S0) still L2-hot.  Phase-1's LDS image lies over the loop's (the stages never
+// overlap); the loop's one persistent LDS word (the zero word) is set again before the loop starts.  A QP with
+// status <= 0 from Phase-1 returns (x0, S, status) as SSQP.jl:230-232 does; a QP Phase-1 does not take (free variables)
+// is left on its list for the workgroup Phase-1 kernel, which hands it on like any hand-over.
+// The LOOP behind a real CALL: inlined next to Phase-1 (500 registers, every one of them clobbered) the two stages are
+// allocated as one function and the loop's hot paths end up with spills they do not have on their own (the pair ran 10 %
+// slower than two launches; with Phase-1 as the callee the loop's values that live across the call were reloaded from
+// scratch at every use, 50 % slower).  As a callee the loop is allocated by itself, exactly like its stand-alone kernel, and
+// the call -- once per QP, nothing of Phase-1 alive across it -- costs the saves of the calling convention.  Arguments of a
+// device function travel in vector registers / memory: everything uniform is pinned back to scalars here.
+template <class T>
+__device__ __forceinline__ T *uni_p(T *p) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ size_t uni_sz(size_t v) { return (size_t)uni_p(reinterpret_cast<char *>(v)); }
+// (The parameters are read where the kernel itself reads them -- the kernel-argument segment, scalar loads the compiler can
+//  re-issue instead of keeping ~45 values alive: as register arguments they cost the callee 5-10 % in scalar spills.)
+typedef const __attribute__((address_space(4))) char *karg_t;   // the kernel-argument segment (constant address space)
+__device__ __attribute__((noinline)) void loop_call(karg_t kargs_, int prob_) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const karg_t kargs = (karg_t)(unsigned long long)uni_p((const char *)(unsigned long long)kargs_);
+    const SolveParams &P = *(const SolveParams *)kargs;   // the kernel's first argument
+    WLds L;
+    double *gscr, *park;
+    wave_carve<false>(P, smem, L, gscr, park);   // (sets the loop's one persistent LDS word: Phase-1's image lay over it)
+    wave_sync();
+    wave_solve_one<false>(P, uni(prob_), L, gscr, park);
+}
+
+// ... and Phase-1 behind a call of its own: the kernel itself is a thin driver with nothing alive across either call, so
+// each stage is allocated exactly as in its stand-alone kernel.
+template <int NC, int MC>
+__device__ __attribute__((noinline)) int phase1_call(karg_t kargs_, int prob_) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const karg_t kargs = (karg_t)(unsigned long long)uni_p((const char *)(unsigned long long)kargs_);
+    constexpr size_t qoff = (sizeof(SolveParams) + alignof(p1w::Params) - 1) / alignof(p1w::Params) * alignof(p1w::Params);
+    const p1w::Params &Q = *(const p1w::Params *)(kargs + qoff);   // the second argument
+    int st = -2;
+    const bool took = p1w::solve_one<NC, MC>(Q, uni(prob_), reinterpret_cast<double *>(smem), st);
+    return took ? st : -100;
+}
+
+template <int NC, int MC>
+__global__ __launch_bounds__(64, 1) void ssqp_full_kernel(SolveParams P, p1w::Params Q) {
+    static_assert(NSL == 2, "the four-per-CU build");
+    const int lane = lane_id();
+    // (a callee cannot ask for the kernel-argument segment itself -- the builtin gives it a null pointer: the kernel hands it on)
+    const karg_t kargs = (karg_t)__builtin_amdgcn_kernarg_segment_ptr();
+    for (;;) {
+        int prob = 0;
+        if (threadIdx.x == 0) prob = (int)atomicAdd(P.queue, 1u);
+        prob = __builtin_amdgcn_readfirstlane(prob);
+        if (prob >= P.nprob) break;
+        const int st1 = uni(phase1_call<NC, MC>(kargs, prob));
+        wave_sync();
+        if (st1 == -100) continue;   // (not taken: on the list of the workgroup Phase-1 kernel)
+        if (st1 <= 0) {  // SSQP.jl:230-232: return x0, S, status
+            const double *x0 = Q.x0 + (size_t)prob * P.N;
+            double *z = P.z + (size_t)prob * P.N;
+            for (int i = lane; i < P.N; i += 64) z[i] = x0[i];
+            if (lane == 0) {
+                P.status[prob] = st1;
+                if (P.detail) P.detail[prob] = st1 < 0 ? SSQP_DETAIL_SINGULAR_LU : SSQP_DETAIL_NONE;
+                if (P.stats) {
+                    ssqp_stats z0;
+                    z0.iters = 0; z0.alg_bytes = 0; z0.read_bytes = 0; z0.alg_flops = 0; z0.sum_k3 = 0; z0.max_k = 0; z0.path = 128;
+                    P.stats[prob] = z0;
+                }
+            }
+            continue;
+        }
+        loop_call(kargs, prob);
+    }
+}
+#endif
 
 }  // namespace
 
+#ifdef SSQP_FULL
+template <int NC, int MC>
+static hipError_t launch_full_t(const SolveParams &P, const p1w::Params &Q, int grid, size_t lds, hipStream_t stream) {
+    static unsigned long long ldsSet = 0ull;
+    hipError_t e = allow_full_lds(reinterpret_cast<const void *>(&ssqp_full_kernel<NC, MC>), &ldsSet);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ssqp_full_kernel<NC, MC>), dim3(grid), dim3(64), lds, stream, P, Q);
+    return hipGetLastError();
+}
+hipError_t launch_solve_full(const SolveParams &P, int grid, const double *A, const double *G, const double *b, const double *g,
+                             double tolLP, double *x0, int32_t *p1status, unsigned int *p1Count, int *p1List, hipStream_t stream) {
+    p1w::Params Q;
+    Q.nprob = P.nprob; Q.N = P.N; Q.M = P.M; Q.J = P.J;
+    Q.A = A; Q.G = G; Q.b = b; Q.g = g; Q.d = P.d; Q.u = P.u;
+    Q.tol = tolLP;
+    Q.x0 = x0; Q.S = P.S; Q.status = p1status;
+    Q.fbCount = p1Count; Q.fbList = p1List;
+    const int M0 = P.M + P.J, N1 = P.N + P.J + M0;
+    // (three builds of the pair: the loop's code is in every one of them)
+    if (M0 <= 4) {
+        if (N1 <= 64 * 5) {
+            const size_t l1 = (size_t)p1w::lds_doubles<5, 4>() * 8, l = l1 > (size_t)P.waveLdsBytes ? l1 : (size_t)P.waveLdsBytes;
+            return launch_full_t<5, 4>(P, Q, grid, l, stream);
+        }
+        const size_t l1 = (size_t)p1w::lds_doubles<9, 4>() * 8, l = l1 > (size_t)P.waveLdsBytes ? l1 : (size_t)P.waveLdsBytes;
+        return launch_full_t<9, 4>(P, Q, grid, l, stream);
+    }
+    const size_t l1 = (size_t)p1w::lds_doubles<9, 11>() * 8, l = l1 > (size_t)P.waveLdsBytes ? l1 : (size_t)P.waveLdsBytes;
+    return launch_full_t<9, 11>(P, Q, grid, l, stream);
+}
+}  // namespace ssqp
+#else
 #if SSQP_WAVE_VARIANT == 0
 #define WV_KERNEL ssqp_wave_kernel<1, false, 2>
 #define WV_LAUNCH launch_wave_v0
@@ -2997,3 +3119,4 @@ extern "C" int ssqp_debug_wave_phases(unsigned long long *out64, int reset) {
     return ssqp::wave_phases_v0(out64, reset) | ssqp::wave_phases_v1(out64, reset) | ssqp::wave_phases_v2(out64, reset);
 }
 #endif
+#endif  // SSQP_FULL

@@ -424,6 +424,28 @@ class DeviceBatch:
             self._ptr(self.gam) if self.gam is not None else None, C.c_void_p(stream))
         _capi.check(rc, self.ctx.handle)
 
+    def solve_full(self, settings=None, settingsLP=None, stream=None):
+        """solveQP(Q) for the batch in ONE launch per QP (ssqp_solve_full_batch_dev_f64): Phase-1 and the loop in the same
+        kernel; S, z, status are outputs (S0 / x0 are not read).  Asynchronous on `stream`."""
+        torch = self.torch
+        cs = _csettings(settings)
+        csl = _csettings(settingsLP if settingsLP is not None else settings)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.S.device).cuda_stream
+        elif not isinstance(stream, int):
+            stream = stream.cuda_stream
+        self.ctx.flush_to(stream)
+        t = self.t
+        for k in "VAGqbgdu":
+            if t[k].shape[0] == 1 and self.P > 1:
+                raise SSQPError("DeviceBatch.solve_full needs per-problem arrays (no stride-0 sharing)")
+        rc = _capi.lib().ssqp_solve_full_batch_dev_f64(
+            self.ctx.handle, self.P, self.N, self.M, self.J, *[self._ptr(t[k]) for k in "VAGqbgdu"],
+            self._ptr(self.S), self._ptr(self.z), C.byref(cs), C.byref(csl), self._ptr(self.status),
+            self._ptr(self.detail), self._ptr(self.stats), self._ptr(self.lam) if self.lam is not None else None,
+            self._ptr(self.gam) if self.gam is not None else None, C.c_void_p(stream))
+        _capi.check(rc, self.ctx.handle)
+
     def phase1(self, settingsLP=None, stream=None):
         """initQP for the whole batch ON the GPU (ssqp_phase1_batch_dev_f64): fills self.x0 / self.S0 in place
         (asynchronous) and returns the status tensor (1 feasible, 0 infeasible, -1 singular basis)."""

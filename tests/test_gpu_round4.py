@@ -65,3 +65,73 @@ def test_multi_context_entry_over_every_device(pkg, orc):
     ctxs = [pkg.Context(d) for d in range(ndev)] + [pkg.Context(0)]
     z, S, status, detail = pkg.solveQP_batch_multi(prob, S0, x0, ctxs)
     assert_parity(z, S, status, zo, So, sto)
+
+
+def _two_stage_reference(pkg, orc, prob):
+    """solveQP(Q) = initQP + the loop (SSQP.jl:224-234) by the host Phase-1 and the oracle's loop"""
+    x0, S0, st = pkg.phase1_batch(prob)
+    P, N = prob["q"].shape
+    z, S, status = x0.copy(), S0.copy(), st.astype(np.int64)
+    ok = st == 1
+    if ok.any():
+        sub = {k: np.ascontiguousarray(v[ok]) for k, v in prob.items()}
+        zo, So, sto, _, _ = oracle_batch(orc, sub, S0[ok], x0[ok])
+        z[ok], S[ok], status[ok] = zo, So, sto
+    return z, S, status, st
+
+
+@pytest.mark.parametrize("name,nprob", [("cfg4", 160), ("cfg3", 48), ("cfg1", 64), ("cfg2", 8)])
+def test_single_launch_solveQP_matches_the_two_stage_path(pkg, orc, name, nprob):
+    """ssqp_solve_full_batch_dev_f64: Phase-1 and the loop in one kernel launch per QP -- z, S, status as from the host
+    Phase-1 followed by the oracle's loop, the multipliers included"""
+    cfg = pkg.CONFIGS[name]
+    prob = pkg.generate_batch(cfg, nprob, 20261005)
+    zr, Sr, str_, st1 = _two_stage_reference(pkg, orc, prob)
+    assert (st1 == 1).all()
+    P, N = prob["q"].shape
+    db = pkg.DeviceBatch(prob, np.zeros((P, N + cfg.J), dtype=np.int32), np.zeros((P, N))).want_multipliers()
+    db.solve_full()
+    r = db.results()
+    assert_parity(r["z"], r["S"], r["status"], zr, Sr, str_)
+    assert ((r["stats"]["path"] & 16) != 0).all()                      # the wavefront kernel's loop ran every QP
+    db.solve_full()                                                    # again on the same buffers: nothing stale
+    r2 = db.results()
+    assert np.array_equal(r2["S"], r["S"]) and np.array_equal(r2["status"], r["status"]) and np.array_equal(r2["z"], r["z"])
+    # the two-launch path on the same context gives the same bits (same loop kernel, same vertex)
+    db2 = pkg.DeviceBatch(prob, np.zeros((P, N + cfg.J), dtype=np.int32), np.zeros((P, N)))
+    db2.phase1()
+    db2.solve()
+    r3 = db2.results()
+    assert np.array_equal(r3["S"], r["S"]) and np.array_equal(r3["status"], r["status"]) and np.array_equal(r3["z"], r["z"])
+
+
+def test_single_launch_solveQP_mixed_outcomes(pkg, orc):
+    """one batch with every way a QP can leave the single launch: solved by the loop; infeasible in Phase-1 (status 0, z = x0,
+    Phase-1's S, SSQP.jl:230-232); free variables (left to the workgroup Phase-1 kernel, then handed to the loop at pass 0);
+    free variables AND infeasible"""
+    cfg = pkg.GenConfig(96, 2, 5, 192, 1e-3, 4.0 / 96, 1.0, 0.1)
+    prob = pkg.generate_batch(cfg, 40, 99)
+    prob["u"][5:10] = 0.5 / cfg.N                    # the budget row cannot be met
+    prob["d"][10:20, :3] = -np.inf                   # free variables
+    prob["u"][10:20, :3] = np.inf
+    prob["u"][18:20, 3:] = 0.25 / cfg.N              # ... and infeasible: the bounded part cannot reach the budget? (free ones can)
+    zr, Sr, str_, st1 = _two_stage_reference(pkg, orc, prob)
+    assert (st1[5:10] == 0).all() and (st1[:5] == 1).all() and (st1[10:18] == 1).all()
+    P, N = prob["q"].shape
+    db = pkg.DeviceBatch(prob, np.zeros((P, N + cfg.J), dtype=np.int32), np.zeros((P, N)))
+    db.solve_full()
+    r = db.results()
+    assert np.array_equal(r["status"], str_), (r["status"], str_)
+    assert np.array_equal(r["S"], Sr)
+    bad = str_ <= 0
+    assert np.array_equal(r["z"][bad], zr[bad])                       # Phase-1's x0, bit for bit
+    assert_parity(r["z"][~bad], r["S"][~bad], r["status"][~bad], zr[~bad], Sr[~bad], str_[~bad])
+    assert ((r["stats"]["path"][10:18] & 32) != 0).all() or ((r["stats"]["path"][10:18] & 64) != 0).all()   # handed over at pass 0
+
+
+def test_single_launch_solveQP_refuses_what_it_is_not_built_for(pkg):
+    cfg = pkg.GenConfig(64, 2, 12, 128, 1e-3, 0.1, 1.0, 0.1)           # M + J = 14 rows
+    prob = pkg.generate_batch(cfg, 4, 1)
+    db = pkg.DeviceBatch(prob, np.zeros((4, 64 + 12), dtype=np.int32), np.zeros((4, 64)))
+    with pytest.raises(pkg.SSQPError):
+        db.solve_full()
