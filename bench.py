@@ -348,8 +348,24 @@ def run(args):
             e2e = {"qps": P / dt, "ms_per_step": 1e3 * dt, "phase1_ms": ev[0].elapsed_time(ev[1]),
                    "loop_ms": ev[1].elapsed_time(ev[2]),
                    "same_S_and_iters": bool(np.array_equal(r2["S"], res["S"]) and np.array_equal(r2["status"], res["status"])),
-                   "note": "ssqp_phase1_batch_dev_f64 + the loop per step, one stream; shapes the GPU Phase-1 is slow "
-                           "on (large M + J) are routed to the host stage by the library"}
+                   "note": "ssqp_phase1_batch_dev_f64 (one wavefront per QP where that kernel applies) + the loop per step, "
+                           "two launches on one stream"}
+            try:   # the same in ONE launch per QP (ssqp_solve_full_batch_dev_f64), where that entry takes the shape
+                batch.solve_full()
+                ctx.sync(main_stream.cuda_stream)
+                torch.cuda.synchronize(dev)
+                ts = time.perf_counter()
+                for i in range(args.steps):
+                    batch.solve_full()
+                ctx.sync(main_stream.cuda_stream)
+                torch.cuda.synchronize(dev)
+                dt1 = (time.perf_counter() - ts) / args.steps
+                r4 = batch.results()
+                e2e["single_launch"] = {"qps": P / dt1, "ms_per_step": 1e3 * dt1,
+                                        "same_S_and_iters": bool(np.array_equal(r4["S"], res["S"]) and
+                                                                 np.array_equal(r4["status"], res["status"]))}
+            except Exception as exc:
+                e2e["single_launch"] = {"error": str(exc)}
             if nlanes > 1 and world == 1 and mode == "lanes":
                 # the same with the launch lanes: Phase-1 and loop of a step on its lane's stream, so one step's
                 # Phase-1 runs beside another step's loop

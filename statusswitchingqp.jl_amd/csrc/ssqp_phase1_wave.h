@@ -293,11 +293,16 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
     const double sgn = rhs >= start ? 1.0 : -1.0;
     if (lane < MC) sg[lane] = sgn;
     wave_sync();
+    // rows of inv(B): lane r < M0 owns row r; the lanes r + M0 g (g < RGRP) hold copies, so that the terms of the xb sum --
+    // M0 rows x the listed columns -- are formed by RGRP M0 lanes at once instead of M0
+    const int RGRP = (M0 * 16 <= 64) ? 16 : 64 / M0;   // (M0 <= 11: at least 5 groups)
+    const int rgrp = lane / M0, rrow = lane - rgrp * M0;
+    const bool rlane = rgrp < RGRP;
     double ivr[MC];
 #pragma unroll
     for (int t = 0; t < MC; ++t) {
-        ivr[t] = (lane == t && lane < M0) ? sgn : 0.0;   // invB = diag(sgn)
-        if (lane < MC) Bc[lane * MC + t] = ivr[t];       // column `lane` of the basis matrix: the artificial column
+        ivr[t] = (rlane && rrow == t) ? sg[rrow] : 0.0;   // invB = diag(sgn)
+        if (lane < MC) Bc[lane * MC + t] = (lane == t && lane < M0) ? sgn : 0.0;   // column `lane` of the basis matrix: the artificial column
     }
     double xb = (lane < M0) ? fabs(start - rhs) : 0.0;
     int bas = N0 + rr;
@@ -545,7 +550,7 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
             }
             wave_sync();
 #pragma unroll
-            for (int t = 0; t < MC; ++t) ivr[t] = (lane < M0 && t < M0) ? T[rr * MC + t] : 0.0;
+            for (int t = 0; t < MC; ++t) ivr[t] = (rlane && t < M0) ? T[rrow * MC + t] : 0.0;
             wave_sync();
             // statuses and values: S[k] = IN, S[leaving] = leaveStatus, x[leaving] = its bound
             {
@@ -568,6 +573,7 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
         }
         // ---- xb = invB * b - Y * x[nonbasic]: the nonbasic columns at a nonzero value, ascending, one rounded multiply and
         // one rounded add per term (Simplex.jl:599)
+        W1_STAMP(8);  // bound flip + the cached term it changes
         double a2 = 0.0;
         if (rebuild || !cached) {  // every term anew (inv(B) has changed)
             // the listed columns, ascending: place of this lane's column of slot c in the list
@@ -578,6 +584,10 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
                 mc[c] = __ballot(((nbw & nzw) >> c) & 1u);
                 n += __popcll(mc[c]);
             }
+#ifdef SSQP_PHASE_PROFILE
+            w1a[12] += n;
+            w1a[13] += 1;
+#endif
             if (n <= TCAP) {
                 // through LDS: the owners put their listed columns (and x_k) side by side in list order -- every listed
                 // column of a slot at once --, then lane r reads a column's entries from ONE address each (a broadcast read)
@@ -598,22 +608,24 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
                 }
                 wave_sync();
                 kkv = (lane < n) ? ib2[lane < n ? lane : 0] : 0x7fffffff;
-                for (int j = 0; j < n; j += 2) {  // (two columns per round: two independent chains of dependent adds)
-                    const bool two = j + 1 < n;
-                    const double *__restrict__ c0 = AL + j * MCP, *__restrict__ c1 = AL + (two ? j + 1 : j) * MCP;
-                    double y0 = 0.0, y1 = 0.0;
+                // lane (row r, group g) forms rows r of the columns j = g, g + RGRP, ...
+                for (int j0 = 0; j0 < n; j0 += RGRP) {  // uniform trip count
+                    const int j = j0 + rgrp;
+                    const bool on = rlane && j < n;
+                    const double *__restrict__ cj = AL + (on ? j : 0) * MCP;
+                    double y = 0.0;
 #pragma unroll
-                    for (int t = 0; t < MC; ++t) {
-                        y0 += ivr[t] * c0[t];
-                        y1 += ivr[t] * c1[t];
-                    }
-                    const double t0 = y0 * c0[MC], t1 = y1 * c1[MC];
-                    a2 += t0;
-                    a2 += two ? t1 : 0.0;   // (+0.0 on a sum that is never -0.0)
-                    if (lane < MC) {
-                        tl[j * MC + lane] = t0;
-                        if (two) tl[(j + 1) * MC + lane] = t1;
-                    }
+                    for (int t = 0; t < MC; ++t) y += ivr[t] * cj[t];
+                    if (on) tl[j * MC + rrow] = y * cj[MC];
+                }
+                wave_sync();
+                // ... and lane r adds its row in list order (one rounded add per term)
+                for (int p0 = 0; p0 < n; p0 += 8) {
+                    double tv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) tv[q] = tl[((p0 + q < n) ? p0 + q : 0) * MC + (lane < MC ? lane : 0)];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a2 += (p0 + q < n) ? tv[q] : 0.0;   // (+0.0 on a sum that is never -0.0)
                 }
                 cached = true;
                 cnt = n;
@@ -638,6 +650,7 @@ __device__ __forceinline__ bool solve_one(const Params &P, int prob, double *lds
                 cnt = 0;
             }
             rebuild = false;
+            W1_STAMP(9);   // xb terms anew
         } else {  // the cached terms, re-added in ascending order of their columns, eight LDS reads per round trip
             for (int p0 = 0; p0 < cnt; p0 += 8) {
                 double tv[8];

@@ -36,10 +36,11 @@ lib.ssqp_debug_phase1_wave_phases(out, 1)
 db.phase1(); db.torch.cuda.synchronize()
 lib.ssqp_debug_phase1_wave_phases(out, 1)
 wn = ["set-up (LP columns into registers, first Y.c)", "pricing + first maximum", "entering column + ratio test",
-      "basis sort + columns", "inv(lu(B)) in registers", "rows of the inverse, statuses", "Y.c refresh", "xb = invB b - Y x"]
-tot = sum(out[:8])
+      "basis sort + columns", "inv(lu(B)) in registers", "rows of the inverse, statuses", "Y.c refresh", "xb: cached terms re-added, invB b", "bound flip + its cached term", "xb terms anew after a pivot"]
+tot = sum(out[:10])
 if tot:
     print("wavefront kernel: simplex passes per QP %.1f, basis changes per QP %.1f, cycles per QP %.0f" % (
         out[14] / nprob, out[15] / nprob, tot / nprob))
+    print("xb rebuilds per QP %.1f, listed columns per rebuild %.1f" % (out[13] / nprob, out[12] / max(out[13], 1)))
     for i, n in enumerate(wn):
         print("%-46s %6.2f %%  %9.0f cycles per QP" % (n, 100.0 * out[i] / tot, out[i] / nprob))
