@@ -103,78 +103,148 @@ __device__ __forceinline__ int compact_columns(int tid, int n, int *list, int *c
     return *cnt;
 }
 
-// inv(lu(a)) in place for the n x n column-major LDS matrix a (scratch x: n x n), partial pivoting, the host's
-// operation order per element (ssqp_host.cpp invert_lu).  Returns false when a pivot is exactly 0.
-__device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, int *piv, int n, int *flag) {
+__device__ __forceinline__ void wave_order() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+// inv(lu(a)) in place for the n x n column-major LDS matrix a, partial pivoting, the host's operation order per element
+// (ssqp_host.cpp invert_lu).  Scratch: x (n x (n + 1) doubles), vec (2 n doubles), piv (2 n ints).  Returns false when a
+// pivot is exactly 0.  Three barriers per elimination step:
+//   * the pivot search of column k is a wavefront reduction (first maximum: value, then smallest row among the ties) --
+//     one thread scanning the column was 4 k cycles of dependent LDS reads per step;
+//   * the pivot row (the U row) and the scaled column (the L column) are staged in `vec`, so that the trailing update reads
+//     nothing another thread writes in the same phase: element (i, j) is read at the row the swap would have brought to i
+//     and written at i -- the swap itself is never a separate pass;
+//   * the columns of the inverse take ONE THREAD each (18 per wavefront), forward and backward substitution in private,
+//     no barrier: the factors are read from one address by every thread (broadcast), the column lives in `x` with a
+//     stride of n + 1 doubles (conflict-free for the eighteen lanes of a wavefront).
+__device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double *vec, int *piv, int n, int *flag) {
+    double *urow = vec, *lcol = vec + n;
+    const int lane = tid & 63;
     for (int k = 0; k < n; ++k) {
-        if (tid == 0) {
-            int p = k;
-            double best = fabs(a[(size_t)k * n + k]);
-            for (int i = k + 1; i < n; ++i) {
+        if (tid < 64) {  // the FIRST largest |a(i, k)|, i = k .. n - 1 (the host's strict ">" scan)
+            double best = -1.0;
+            int bi = 0x7fffffff;
+            for (int i = k + lane; i < n; i += 64) {
                 const double v = fabs(a[(size_t)k * n + i]);
-                if (v > best) best = v, p = i;
+                if (v > best) best = v, bi = i;   // (ascending i inside the lane)
             }
-            piv[k] = p;
-            *flag = (best == 0.0) ? 0 : 1;
+            const KeyMin km = wave_keymin(KeyMin{-best, bi});
+            if (lane == 0) {
+                piv[k] = km.ord;
+                *flag = (km.v == 0.0) ? 0 : 1;   // (-best == -0.0: the whole column is zero)
+            }
         }
         __syncthreads();
         if (!*flag) return false;
         const int p = piv[k];
-        if (p != k)
+        // stage the pivot row (columns k .. n - 1 of old row p) and the scaled column (rows k + 1 .. n - 1, post-swap order);
+        // columns j < k: the L part of rows k and p changes places
+        {
+            const double r = 1.0 / a[(size_t)k * n + p];   // (every thread: cheaper than a broadcast through LDS and a barrier)
             for (int j = tid; j < n; j += NT1) {
-                const double t = a[(size_t)j * n + k];
-                a[(size_t)j * n + k] = a[(size_t)j * n + p];
-                a[(size_t)j * n + p] = t;
+                if (j >= k) urow[j] = a[(size_t)j * n + p];
+                else if (p != k) {
+                    const double t = a[(size_t)j * n + k];
+                    a[(size_t)j * n + k] = a[(size_t)j * n + p];
+                    a[(size_t)j * n + p] = t;
+                }
             }
+            for (int i = k + 1 + tid; i < n; i += NT1) {
+                const int src = (i == p) ? k : i;                   // (the row the swap brings to i)
+                lcol[i] = a[(size_t)k * n + src] * r;               // a(i, k) *= r
+            }
+        }
         __syncthreads();
-        const double r = 1.0 / a[(size_t)k * n + k];
-        __syncthreads();
-        for (int i = k + 1 + tid; i < n; i += NT1) a[(size_t)k * n + i] *= r;
-        __syncthreads();
-        const int w = n - k - 1;
-        for (int e = tid; e < w * w; e += NT1) {
-            const int i = k + 1 + e % w, j = k + 1 + e / w;
-            a[(size_t)j * n + i] -= a[(size_t)k * n + i] * a[(size_t)j * n + k];
+        // trailing update a(i, j) -= a(i, k) * a(k, j) for i, j > k, reading (i, j) where the swap would have put it; the
+        // thread that handles row p of a column also writes row k of it (the pivot row), and column k takes the L column.
+        // Thread (cj = tid >> 4, ri = tid & 15) takes the rows k + 1 + ri + 16 m of the columns k + 1 + cj + 16 g: no
+        // integer division per element, sixteen neighbours read 128 contiguous bytes, and a column's rows (five at most for
+        // n <= 80, in rounds of five beyond) go out in one LDS round trip
+        {
+            const int cj = tid >> 4, ri = tid & 15;
+            for (int j = k + 1 + cj; j < n; j += NT1 / 16) {
+                const double uj = urow[j];
+                double *colj = a + (size_t)j * n;
+                for (int i0 = k + 1 + ri; i0 < n; i0 += 16 * 5) {
+                    double ov[5], lv[5];
+#pragma unroll
+                    for (int m = 0; m < 5; ++m) {
+                        const int i = i0 + 16 * m < n ? i0 + 16 * m : i0;
+                        ov[m] = colj[(i == p) ? k : i];
+                        lv[m] = lcol[i];
+                    }
+#pragma unroll
+                    for (int m = 0; m < 5; ++m) {
+                        const int i = i0 + 16 * m;
+                        if (i < n) {
+                            colj[i] = ov[m] - lv[m] * uj;
+                            if (i == p) colj[k] = uj;
+                        }
+                    }
+                }
+            }
+            for (int i = k + 1 + tid; i < n; i += NT1) a[(size_t)k * n + i] = lcol[i];
+            if (tid == 0) a[(size_t)k * n + k] = urow[k];
         }
         __syncthreads();
     }
-    // columns of the inverse: L U x_c = P e_c for every column c with the host's operations per ELEMENT (x_c[i] takes its
-    // updates in the host's order k = 0 .. i - 1 forward, k = n - 1 .. i + 1 backward, then its division), but all the
-    // elements (c, i) a step touches are updated together: the host's "if (t != 0)" guard only skips subtractions of
-    // exact zeros, which change nothing.  P e_c: the host applies the row swaps to e_c in order; the permuted unit
-    // vector has its 1 where that sequence of swaps sends index c.
-    for (int c = tid; c < n; c += NT1) {
-        int pos = c;
-        for (int k = 0; k < n; ++k) {
-            const int pk = piv[k];
-            if (pk != k) pos = (pos == k) ? pk : ((pos == pk) ? k : pos);
+    // columns of the inverse: L U x_c = P e_c, THREE lanes of one wavefront per column (lane q takes the rows i = q mod 3), 21
+    // columns per wavefront: between two steps the three only need the wavefront's own LDS ordering, no barrier.  P e_c: the
+    // host applies the row swaps to e_c in order; the permuted unit vector has its 1 where that sequence of swaps sends c
+    const int xs = n + 1;
+    {
+        const int wv = tid >> 6;
+        const int c = wv * 21 + lane / 3, q = lane % 3;
+        const bool mine = lane < 63 && c < n;
+        double *xc = x + (size_t)(mine ? c : 0) * xs;
+        if (mine) {
+            int pos = c;
+            for (int k = 0; k < n; ++k) {
+                const int pk = piv[k];
+                if (pk != k) pos = (pos == k) ? pk : ((pos == pk) ? k : pos);
+            }
+            for (int i = q; i < n; i += 3) xc[i] = (i == pos) ? 1.0 : 0.0;
         }
-        piv[n + c] = pos;  // (second half of piv: scratch)
+        wave_order();
+        // x[i] -= f[i] * t for this lane's rows of lo .. hi - 1, eight per LDS round trip (the compiler cannot tell that the
+        // stores to x do not alias the factors and would wait for every element's own read - modify - write)
+        auto axpy = [&](const double *f, int lo, int hi, double t) {
+            int first = lo + ((q - lo) % 3 + 3) % 3;   // the first row >= lo with i = q mod 3
+            for (int i0 = first; i0 < hi; i0 += 24) {
+                double fv[8], xv[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int i = i0 + 3 * m < hi ? i0 + 3 * m : i0;
+                    fv[m] = f[i];
+                    xv[m] = xc[i];
+                }
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    if (i0 + 3 * m < hi) xc[i0 + 3 * m] = xv[m] - fv[m] * t;
+            }
+        };
+        // (every wavefront walks all n steps -- the step count is uniform -- whether or not a lane has a column)
+        for (int k = 0; k < n; ++k) {  // forward: x[i] -= L(i, k) x[k]  for i > k  (the host's "t != 0" guard only skips zeros)
+            const double t = xc[k];
+            if (mine) axpy(a + (size_t)k * n, k + 1, n, t);
+            wave_order();
+        }
+        for (int k = n - 1; k >= 0; --k) {  // backward: x[k] /= U(k, k), then x[i] -= U(i, k) x[k]  for i < k
+            const double t = xc[k] / a[(size_t)k * n + k];
+            wave_order();   // (the three lanes have read x[k])
+            if (mine) {
+                if (k % 3 == q) xc[k] = t;
+                axpy(a + (size_t)k * n, 0, k, t);
+            }
+            wave_order();
+        }
     }
     __syncthreads();
     for (int e = tid; e < n * n; e += NT1) {
-        const int c = e / n, i = e - c * n;
-        x[e] = (piv[n + c] == i) ? 1.0 : 0.0;
+        const int cc = e / n, i = e - cc * n;
+        a[e] = x[(size_t)cc * xs + i];
     }
-    __syncthreads();
-    for (int k = 0; k < n; ++k) {  // forward: x_c[i] -= L(i, k) x_c[k]  for i > k
-        const int w = n - k - 1;
-        for (int e = tid; e < n * w; e += NT1) {
-            const int c = e / w, i = k + 1 + (e - c * w);
-            x[(size_t)c * n + i] -= a[(size_t)k * n + i] * x[(size_t)c * n + k];
-        }
-        __syncthreads();
-    }
-    for (int k = n - 1; k >= 0; --k) {  // backward: x_c[k] /= U(k, k), then x_c[i] -= U(i, k) x_c[k]  for i < k
-        for (int c = tid; c < n; c += NT1) x[(size_t)c * n + k] /= a[(size_t)k * n + k];
-        __syncthreads();
-        for (int e = tid; e < n * k; e += NT1) {
-            const int c = e / k, i = e - c * k;
-            x[(size_t)c * n + i] -= a[(size_t)k * n + i] * x[(size_t)c * n + k];
-        }
-        __syncthreads();
-    }
-    for (int e = tid; e < n * n; e += NT1) a[e] = x[e];
     __syncthreads();
     return true;
 }
@@ -189,10 +259,6 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, int *pi
 // and their order exactly as above.  Called by the lanes of the first wavefront; returns false (to all of them) when a
 // pivot is exactly 0.
 constexpr int LUC = 12;
-__device__ __forceinline__ void wave_order() {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-}
 __device__ __forceinline__ bool invert_lu_cols(double *a, double *lbuf, int *piv, int n) {
     const int j = threadIdx.x & 63;
     const bool mine = j < n;
@@ -331,6 +397,8 @@ struct P1Params {
     ssqp_stats *stats;
 };
 
+// BIG: the build for many rows (M0 > 12), one workgroup per CU: twice the registers, spent on wider tiles of the Y . c refresh
+template <bool BIG>
 __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob, unsigned char *smem) {
     const int tid = threadIdx.x;
     P1_DECL;
@@ -348,7 +416,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
     // ---- LDS: invB, Bm (M0 x M0 each), rhs, xb, pvec, start (M0 each), small integers
     double *invB = reinterpret_cast<double *>(smem);
     double *Bm = invB + (size_t)M0 * M0;
-    double *rhs = Bm + (size_t)M0 * M0;
+    double *rhs = Bm + (size_t)M0 * (M0 + 1);      // (Bm: M0 x (M0 + 1), the padded columns of the inverse while they are formed)
     double *xb = rhs + M0;
     double *pv = xb + M0;
     double *acc = pv + M0;
@@ -533,25 +601,72 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                 if (doB) sdot[kb] = sdB;
             }
         } else {
-            for (int k = tid; k < N1; k += NT1) {
-                if (!general(k)) continue;
-                if (!nonbasic[k]) continue;
-                const double *ak = A1 + k;  // (entry t of column k: ak[t * N1])
-                double sd = 0.0;
-                // (four rows at a time: the four sums are independent chains, each in the host's order over t)
-                for (int r0 = 0; r0 < M0; r0 += 4) {
-                    double s4[4] = {0.0, 0.0, 0.0, 0.0};
-                    for (int t = 0; t < M0; ++t) {
-                        const double at = ak[(size_t)t * N1];
+            // Many rows (M0 > 12; cfg5: 72): only the rows whose basic variable is ARTIFICIAL count -- c[basis[r]] is 0 for the
+            // others, and s * 0.0 = +-0.0 changes no bit of a sum that started at +0.0 and so is never -0.0 (only an Inf / NaN
+            // row sum would have left a NaN behind) -- and they go SIX at a time over FOUR columns per thread: 24 independent
+            // accumulation chains, every entry of the LP fetched once per six rows and every entry of inv(B) once per four
+            // columns (the first version walked one column with four rows and a dependent global load per term: 6.2 M cycles
+            // per refresh at M0 = 72, 80 % of cfg5's Phase-1).  Per element the sums keep the host's order: t ascending inside
+            // a row, rows ascending.
+            int *art = piv;   // (the LU's integer scratch is idle here)
+            const int nArt = compact_columns(tid, M0, art, &misc[0], [&](int r) { return basis[r] >= N0; });
+            constexpr int RG = BIG ? 8 : 6, CG = 4;
+            for (int kb = 0; kb < N1; kb += CG * NT1) {
+                int kc[CG];
+                bool on[CG];
+                bool anyOn = false;
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (r0 + u < M0) s4[u] += invB[(size_t)t * M0 + r0 + u] * at;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (r0 + u < M0) sd += s4[u] * acc[r0 + u];
+                for (int u = 0; u < CG; ++u) {
+                    const int k = kb + tid + u * NT1;
+                    on[u] = general(k) && nonbasic[k < N1 ? k : 0];
+                    kc[u] = on[u] ? k : 0;   // (a column that is not wanted reads column 0: its sums are dropped)
+                    anyOn = anyOn || on[u];
                 }
-                sdot[k] = sd;
+                double sd[CG];
+#pragma unroll
+                for (int u = 0; u < CG; ++u) sd[u] = 0.0;
+                if (anyOn) {
+                    for (int g0 = 0; g0 < nArt; g0 += RG) {
+                        int rr[RG];
+                        double wt[RG];
+#pragma unroll
+                        for (int v = 0; v < RG; ++v) {
+                            rr[v] = art[g0 + v < nArt ? g0 + v : g0];
+                            wt[v] = g0 + v < nArt ? 1.0 : 0.0;   // (a group's unused places repeat its first row with weight 0)
+                        }
+                        double sacc[RG][CG];
+#pragma unroll
+                        for (int v = 0; v < RG; ++v)
+#pragma unroll
+                            for (int u = 0; u < CG; ++u) sacc[v][u] = 0.0;
+                        // (the LP's entries of step t + 1 are requested before step t's products are formed: with one
+                        //  workgroup on the chip nobody else hides the L2 round trip)
+                        double at[CG], an[CG];
+#pragma unroll
+                        for (int u = 0; u < CG; ++u) at[u] = A1[kc[u]];
+                        for (int t = 0; t < M0; ++t) {
+                            const int tn = t + 1 < M0 ? t + 1 : t;
+#pragma unroll
+                            for (int u = 0; u < CG; ++u) an[u] = A1[(size_t)tn * N1 + kc[u]];
+                            double iv[RG];
+#pragma unroll
+                            for (int v = 0; v < RG; ++v) iv[v] = invB[(size_t)t * M0 + rr[v]];
+#pragma unroll
+                            for (int v = 0; v < RG; ++v)
+#pragma unroll
+                                for (int u = 0; u < CG; ++u) sacc[v][u] += iv[v] * at[u];
+#pragma unroll
+                            for (int u = 0; u < CG; ++u) at[u] = an[u];
+                        }
+#pragma unroll
+                        for (int v = 0; v < RG; ++v)
+#pragma unroll
+                            for (int u = 0; u < CG; ++u) sd[u] += sacc[v][u] * wt[v];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < CG; ++u)
+                    if (on[u]) sdot[kc[u]] = sd[u];
             }
         }
         __syncthreads();
@@ -608,8 +723,19 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
 #pragma unroll
                 for (int t = 0; t < MC; ++t)
                     if (t < M0) s += iv[t] * av[t];
-            } else {
-                for (int t = 0; t < M0; ++t) s += invB[(size_t)t * M0 + r] * ak[(size_t)t * N1];
+            } else {  // (eight terms per memory round trip, added in order)
+                for (int t0 = 0; t0 < M0; t0 += 8) {
+                    double iv8[8], av8[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int t = t0 + q < M0 ? t0 + q : t0;
+                        iv8[q] = invB[(size_t)t * M0 + r];
+                        av8[q] = ak[(size_t)t * N1];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (t0 + q < M0) s += iv8[q] * av8[q];
+                }
             }
             pv[r] = s;
         }
@@ -749,7 +875,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                 __syncthreads();
                 okLu = misc[1] != 0;
             } else {
-                okLu = invert_lu(tid, invB, Bm, piv, M0, &misc[1]);
+                okLu = invert_lu(tid, invB, Bm, terms, piv, M0, &misc[1]);   // (terms: idle here, >= 2 M0 doubles)
             }
             if (!okLu) {  // lu() of the reference throws (Simplex.jl:590)
                 status = -1;
@@ -800,8 +926,19 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
 #pragma unroll
                         for (int t2 = 0; t2 < MC; ++t2)
                             if (t2 < M0) y += iv[t2] * av[t2];
-                    } else {
-                        for (int t2 = 0; t2 < M0; ++t2) y += invB[(size_t)t2 * M0 + r] * A1[(size_t)t2 * N1 + kk];
+                    } else {  // (eight terms per memory round trip, added in order)
+                        for (int t0 = 0; t0 < M0; t0 += 8) {
+                            double iv8[8], av8[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const int t2 = t0 + q < M0 ? t0 + q : t0;
+                                iv8[q] = invB[(size_t)t2 * M0 + r];
+                                av8[q] = A1[(size_t)t2 * N1 + kk];
+                            }
+#pragma unroll
+                            for (int q = 0; q < 8; ++q)
+                                if (t0 + q < M0) y += iv8[q] * av8[q];
+                        }
                     }
                     terms[(size_t)t * M0 + r] = y * x[kk];
                 }
@@ -832,7 +969,18 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                     for (int t = 0; t < MC; ++t)
                         if (t < M0) s += iv[t] * rv[t];
                 } else {
-                    for (int t = 0; t < M0; ++t) s += invB[(size_t)t * M0 + r] * rhs[t];
+                    for (int t0 = 0; t0 < M0; t0 += 8) {
+                        double iv8[8], rv8[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int t = t0 + q < M0 ? t0 + q : t0;
+                            iv8[q] = invB[(size_t)t * M0 + r];
+                            rv8[q] = rhs[t];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if (t0 + q < M0) s += iv8[q] * rv8[q];
+                    }
                 }
                 xb[r] = s - a2;
             }
@@ -898,12 +1046,13 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
     }
 }
 
-__global__ __launch_bounds__(NT1, 4) void ssqp_phase1_kernel(P1Params P) {  // (four workgroups per CU: 1,024 QPs resident)
+template <bool BIG>
+__global__ __launch_bounds__(NT1, BIG ? 2 : 4) void ssqp_phase1_kernel(P1Params P) {  // (four workgroups per CU: 1,024 QPs resident)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // one QP per workgroup; on a list (what the wavefront kernel left) a bounded grid strides over it
     const int n = P.list ? (int)*P.listCount : P.nprob;
     for (int it = blockIdx.x; it < n; it += gridDim.x) {
-        phase1_one_wg(P, P.list ? P.list[it] : it, smem);
+        phase1_one_wg<BIG>(P, P.list ? P.list[it] : it, smem);
         __syncthreads();
     }
 }
@@ -920,7 +1069,7 @@ size_t phase1_ws_ints(int N, int M, int J) {
 }
 size_t phase1_lds_bytes(int M, int J) {  // without the N1-vectors
     const size_t M0 = (size_t)(M + J);
-    return (2 * M0 * M0 + 7 * M0 + 4 + p1::XB_CHUNK * M0) * 8 + (3 * M0 + 4 + 8) * 4 + 64;
+    return (2 * M0 * M0 + 8 * M0 + 4 + p1::XB_CHUNK * M0) * 8 + (3 * M0 + 4 + 8) * 4 + 64;
 }
 // with x, colnorm, sdot, S1, nonbasic of up to N1x = 2N + J + M0 columns in LDS
 static size_t phase1_lds_bytes_vec(int N, int M, int J) {
@@ -948,11 +1097,17 @@ hipError_t launch_phase1(int nprob, int N, int M, int J, const double *A, const 
         P.ldsVec = 1;
         lds = phase1_lds_bytes_vec(N, M, J);
     }
-    static unsigned long long ldsSet = 0ull;
-    hipError_t e = allow_full_lds(reinterpret_cast<const void *>(&p1::ssqp_phase1_kernel), &ldsSet);
-    if (e != hipSuccess) return e;
+    static unsigned long long ldsSet = 0ull, ldsSetBig = 0ull;
     const int grid = (list && gridCap > 0 && gridCap < nprob) ? gridCap : nprob;
-    hipLaunchKernelGGL(p1::ssqp_phase1_kernel, dim3(grid), dim3(p1::NT1), lds, stream, P);
+    if (M + J > 12) {   // many rows: the build with the wide refresh tiles
+        hipError_t e = allow_full_lds(reinterpret_cast<const void *>(&p1::ssqp_phase1_kernel<true>), &ldsSetBig);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(p1::ssqp_phase1_kernel<true>, dim3(grid), dim3(p1::NT1), lds, stream, P);
+        return hipGetLastError();
+    }
+    hipError_t e = allow_full_lds(reinterpret_cast<const void *>(&p1::ssqp_phase1_kernel<false>), &ldsSet);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(p1::ssqp_phase1_kernel<false>, dim3(grid), dim3(p1::NT1), lds, stream, P);
     return hipGetLastError();
 }
 
