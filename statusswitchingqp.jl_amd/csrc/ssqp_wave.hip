@@ -1383,6 +1383,9 @@ struct WCtx {
     ssqp_trace *trace;
     int ntrace;
     double *lamOut, *gamOut;  // this QP's multiplier outputs (null: not requested)
+    const float *V32;         // big-factor build: this QP's V rounded to fp32 (column i at V32 + i N), or null (N > 256)
+    double vmax;              // max |V_ij| (what the screening's error bound needs)
+    long long nScreen, nCand; // (statistics: screened passes, exact columns they asked for)
     int RC;
     long long iter, ret;
     int det;
@@ -1811,9 +1814,10 @@ __device__ __forceinline__ void gamma_stream(const WCtx &C, const WLds &L, const
 }
 
 // entry e (uniform, e < 128) of a list held two entries per lane (lane l: entries l and 64 + l): no LDS round trip
-__device__ __forceinline__ int list_get(const int (&v)[2], int e) {
+__device__ __forceinline__ int list_get(const int (&v)[3], int e) {
     const int a = __builtin_amdgcn_readlane(v[0], e & 63), b = __builtin_amdgcn_readlane(v[1], e & 63);
-    return e < 64 ? a : b;
+    const int c = __builtin_amdgcn_readlane(v[2], e & 63);
+    return e < 64 ? a : (e < 128 ? b : c);
 }
 
 // The same gamma when the free variables outnumber the bound ones (K > N - K): V is symmetric, so V[b, F] alpha is the
@@ -1821,7 +1825,8 @@ __device__ __forceinline__ int list_get(const int (&v)[2], int e) {
 // free variable (the multipliers are only ever looked at on the bound variables, SSQP.jl:139-147).  The kept rows of
 // [A;G] go in as before.  Four columns per round: their sums come out of one multi-vector butterfly and are added to the
 // lanes that own those elements of gam.  N <= 128 NI.
-template <int SL, int NI>
+// ROWS = false: the rows of [A;G] are in gam already; Sp then marks (as "not IN") exactly the variables whose column is wanted.
+template <int SL, int NI, bool ROWS = true>
 __device__ __forceinline__ void gamma_dot_stream(const WCtx &C, const WLds &L, const Rows &R, int Kin, int Win,
                                                  const double (&alpha)[NSL], double alRow, int raLane, double2 (&gam)[NCH],
                                                  unsigned Sp) {
@@ -1859,13 +1864,13 @@ __device__ __forceinline__ void gamma_dot_stream(const WCtx &C, const WLds &L, c
     nb = uni(nb);
     wave_sync();
     // ---- hq + [A;G][kept,:]' alphaL by the column stream (no free column: K = 0 there)
-    gamma_stream<SL, NI>(C, L, R, 0, Win, alpha, alRow, raLane, gam);
+    if (ROWS) gamma_stream<SL, NI>(C, L, R, 0, Win, alpha, alRow, raLane, gam);
     if (nb == 0) return;
     // ---- the bound columns, four per round
     const int ngrp = (nb + 3) >> 2;
-    int bv[2];  // (the list in registers, two entries per lane: no LDS round trip per column address)
+    int bv[3];  // (the list in registers, three entries per lane: no LDS round trip per column address)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < 3; ++h) {
         const int e = lane + 64 * h;
         bv[h] = blist[e < nb ? e : nb - 1];
     }
@@ -1914,6 +1919,153 @@ __device__ __forceinline__ void gamma_dot_stream(const WCtx &C, const WLds &L, c
             }
         }
     }
+}
+
+// ---- fp32 screening of the multiplier pass (big-factor build, N <= 256) ----
+// KKTchk! (SSQP.jl:136-188) releases ONE bound variable, the one with the smallest event value L (L = -gamma at an upper
+// bound, gamma at a lower one) among those below -tolG; the pass streams a column of V per bound variable for it -- the
+// largest single stream of a big-factor pass.  Here the columns come from an fp32 COPY of V (half the bytes, packed fp32
+// arithmetic) and only decide WHICH columns are worth an exact look: with |g32_b - gamma_b| <= band for every b (band from
+// the rounding analysis below, twice over), the variable KKTchk! picks is among those with L32 <= min L32 + 2 band, and
+// no variable with L32 >= -tolG + band is a violator at all.  Those few columns (one to three, typically) are then
+// formed exactly, in f64, as before: every decision is taken on exact values, the fp32 pass only prunes.
+// band: g32 = fl(fl(gam0) + sum_f fl(v_bf) fl(alpha_f)) in fp32, any order; with T = vmax * sum|alpha| >= sum|v alpha|:
+// conversions 2 u T, products u T, K - 1 adds (K - 1) u T, gam0's conversion and final add 2 u |gam0| + u T, u = 2^-24
+// => |g32 - gamma| <= u ((K + 4) T + 2 max|gam0|); band is twice that.
+// Returns the candidates as a mask over the lane's 8 variables; ncand = their number (-1: too many, take the exact pass).
+template <int SL>
+__device__ __forceinline__ unsigned gamma32_screen(WCtx &C, const WLds &L, const Rows &R, int Kin, const double (&alpha)[NSL],
+                                                   const double2 (&gam)[NCH], unsigned Sp, double tolG, int &ncand) {
+    constexpr int D = 8;            // ring slots of 1 KiB (one fp32 column each); the upper half of the ring is scratch
+    const int lane = lane_id();
+    const int N = uni(C.N), K = uni(Kin);
+    float *scr = reinterpret_cast<float *>(const_cast<double *>(L.ring) + 1024);   // 8 KiB in: alpha32 (1 KiB), g32 (1 KiB)
+    float *g32L = scr + 256;
+    // ---- alpha as a dense fp32 vector (piece layout: lane l holds elements 4 l .. 4 l + 3), sum |alpha|
+    *reinterpret_cast<float4 *>(scr + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4 *>(g32L + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
+    wave_sync();
+    double a1 = 0.0;
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+        const int r = lane + KSLOT * t;
+        if (r < K) {
+            scr[R.ord[t]] = (float)alpha[t];
+            a1 += fabs(alpha[t]);
+        }
+    }
+    a1 = wave_sum(a1);
+    wave_sync();
+    const float4 ad = *reinterpret_cast<const float4 *>(scr + 4 * lane);
+    // ---- the bound variables, listed in LDS (tr is idle here), then in registers
+    int16_t *blist = reinterpret_cast<int16_t *>(L.tr);
+    int nb = 0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {   // (N <= 256: two chunks)
+        const int i0 = 2 * lane + 128 * m;
+        const bool bx = i0 < N && st_of(Sp, 2 * m) != SSQP_IN, by = i0 + 1 < N && st_of(Sp, 2 * m + 1) != SSQP_IN;
+        const unsigned long long mx = __ballot(bx), my = __ballot(by);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const int pos = nb + __popcll(mx & lt) + __popcll(my & lt);
+        if (bx) blist[pos] = (int16_t)i0;
+        if (by) blist[pos + (bx ? 1 : 0)] = (int16_t)(i0 + 1);
+        nb += __popcll(mx) + __popcll(my);
+    }
+    nb = uni(nb);
+    wave_sync();
+    if (nb > 0) {
+        const int ngrp = (nb + 3) >> 2;
+        int bv[3];
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            const int e = lane + 64 * h;
+            bv[h] = blist[e < nb ? e : nb - 1];
+        }
+        auto colof = [&](int e) -> const double * {   // (as a double pointer for the DMA helper: N floats = N / 2 doubles)
+            return reinterpret_cast<const double *>(C.V32 + (size_t)list_get(bv, e < nb ? e : nb - 1) * N);
+        };
+        const unsigned vo = (unsigned)(4 * lane < N ? 4 * lane : 0) * 4u;   // this lane's 16 bytes of a column
+        auto issue = [&](int slot, const double *col) {
+            glds16_s(uni_ptr(col), vo, L.ringAddr + (unsigned)slot * 1024u);
+        };
+        constexpr int DB = D / 4;
+        for (int g = 0; g < DB && g < ngrp; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) issue((4 * g + u) % D, colof(4 * g + u));
+        wait_all_landed();
+        const bool in = 4 * lane < N;   // (N a multiple of 4)
+        for (int g = 0; g < ngrp; ++g) {
+            if (g + DB <= ngrp) wait_vm<D - 4>();  // (DB - 1 younger groups are in flight)
+            else wait_vm<0>();
+            float prod[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(L.ring) + ((4 * g + u) % D) * 256 + 4 * lane);
+                const float sacc = fmaf(v.w, ad.w, fmaf(v.z, ad.z, fmaf(v.y, ad.y, v.x * ad.x)));
+                prod[u] = in ? sacc : 0.f;
+            }
+            wait_lds();
+            if (g + DB < ngrp) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) issue((4 * g + u) % D, colof(4 * (g + DB) + u));
+            }
+            // four wavefront sums: two halving steps, then the in-row and cross-row steps on one value per lane class
+            const bool b0 = lane & 1, b1 = lane & 2;
+            float r0 = (b0 ? prod[2] : prod[0]) + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b0 ? prod[0] : prod[2]), DPP_XOR1, 0xF, 0xF, false));
+            float r1 = (b0 ? prod[3] : prod[1]) + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b0 ? prod[1] : prod[3]), DPP_XOR1, 0xF, 0xF, false));
+            float q = (b1 ? r1 : r0) + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b1 ? r0 : r1), DPP_XOR2, 0xF, 0xF, false));
+            q += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q), 0x124, 0xF, 0xF, false));  // row_ror:4
+            q += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q), 0x128, 0xF, 0xF, false));  // row_ror:8
+            q += __builtin_bit_cast(float, bperm_i(__builtin_bit_cast(int, q), lane ^ 16));
+            q += __builtin_bit_cast(float, bperm_i(__builtin_bit_cast(int, q), lane ^ 32));
+            // (class (b0, b1) holds the sum of column u = 2 b0 + b1: lanes 0 .. 3 write the four sums; the variable's id is
+            //  fetched per lane -- its list position differs between the classes -- with every lane active)
+            {
+                const int e = 4 * g + 2 * (lane & 1) + ((lane >> 1) & 1);
+                const int ia = bperm_i(bv[0], e & 63), ib = bperm_i(bv[1], e & 63), ic = bperm_i(bv[2], e & 63);
+                const int vid = e < 64 ? ia : (e < 128 ? ib : ic);
+                if (lane < 4 && e < nb) g32L[vid & 255] = q;
+            }
+        }
+    }
+    wave_sync();
+    // ---- screening on the lane's eight variables (dense layout: elements 2 l, 2 l + 1 of chunks 0, 1)
+    double gmx = 0.0;
+    float lv[4];
+    bool bd[4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int i0 = 2 * lane + 128 * m;
+        const float2 gs = *reinterpret_cast<const float2 *>(g32L + (i0 < N ? i0 : 0));
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int s = st_of(Sp, 2 * m + e);
+            const double g0 = e ? gam[m].y : gam[m].x;
+            const float g = (float)g0 + (e ? gs.y : gs.x);
+            bd[2 * m + e] = i0 + e < N && s != SSQP_IN;
+            lv[2 * m + e] = (s == SSQP_UP) ? -g : g;
+            gmx = bd[2 * m + e] ? fmax(gmx, fabs(g0)) : gmx;
+        }
+    }
+    gmx = wave_max(gmx);
+    const double band = 0x1.0p-23 * ((double)(K + 4) * C.vmax * a1 + 2.0 * gmx);
+    const double thr = -tolG + band;
+    double lmin = INF;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lmin = (bd[k] && (double)lv[k] < thr) ? fmin(lmin, (double)lv[k]) : lmin;
+    lmin = wave_min(lmin);
+    unsigned cm = 0;
+    int nc = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool c = bd[k] && (double)lv[k] < thr && (double)lv[k] <= lmin + 2.0 * band;
+        cm |= c ? 1u << k : 0u;
+        nc += __popcll(__ballot(c));
+    }
+    C.sRead += 4ll * N * nb;
+    C.nScreen += 1;
+    ncand = nc > 48 ? -1 : nc;
+    return cm;
 }
 
 // One pass for K > 0 with the kept factor in sync.  SSQP.jl:287-375.
@@ -2168,7 +2320,29 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
     double2 gam[NCH];
 #pragma unroll
     for (int m = 0; m < NCH; ++m) gam[m] = S.hq[m];
-    if (NSL > 2) {  // (big-factor build: the list below streamed through the LDS ring)
+    unsigned candMask = 0xFFu;   // the lane's variables KKTchk! looks at (all, unless the fp32 screening pruned)
+    bool screened = false;
+    if (NSL > 2 && SL >= 2 && C.V32 != nullptr) {
+        // rows of [A;G] first (exact), then the fp32 screening of the bound columns, then the few exact columns it asks for
+        gamma_stream<SL, 2>(C, L, R, 0, W, alpha, alRow, raLane, gam);
+        int ncand = 0;
+        const unsigned cm = gamma32_screen<SL>(C, L, R, K, alpha, gam, S.Sp, tolG, ncand);
+        if (ncand >= 0) {
+            screened = true;
+            candMask = cm;
+            if (ncand > 0) {  // exact gamma of the candidates: their columns only (a status word that marks just them as bound)
+                unsigned spc = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) spc |= (unsigned)(((cm >> k) & 1u) ? SSQP_DN : SSQP_IN) << (4 * k);
+                gamma_dot_stream<SL, 2, false>(C, L, R, K, W, alpha, alRow, raLane, gam, spc);
+            }
+            C.nCand += ncand;
+            C.sRead += 8ll * N * (ncand + W);
+        } else {
+            gamma_dot_stream<SL, 2, false>(C, L, R, K, W, alpha, alRow, raLane, gam, S.Sp);   // (every bound column, exactly)
+            C.sRead += 8ll * N * (N - K + W);
+        }
+    } else if (NSL > 2) {  // (big-factor build: the list below streamed through the LDS ring)
         if (SL >= 2 && N <= 256 && 2 * K > N) {  // fewer bound than free variables: by the bound columns (V is symmetric)
             if (N <= 128) gamma_dot_stream<SL, 1>(C, L, R, K, W, alpha, alRow, raLane, gam, S.Sp);
             else gamma_dot_stream<SL, 2>(C, L, R, K, W, alpha, alRow, raLane, gam, S.Sp);
@@ -2235,7 +2409,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
             const int i = 2 * lane + 128 * m + e;
             const double g = e ? gam[m].y : gam[m].x;
             const int s = st_of(S.Sp, 2 * m + e);
-            if (i < N) {
+            if (i < N && ((candMask >> (2 * m + e)) & 1u)) {
                 if (s == SSQP_UP && g > tolG) ev = keymin(ev, KeyMin{-g, i});        // :141-143
                 else if (s == SSQP_DN && g < -tolG) ev = keymin(ev, KeyMin{g, i});  // :144-146
             }
@@ -2350,6 +2524,11 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
     }
     // ---- optimal: the multipliers of this pass leave the kernel when asked for (alphaL SSQP.jl:351, gamma :352)
     if (C.lamOut && lane < MJ) C.lamOut[lane] = lamRow;
+    if (NSL > 2 && SL >= 2 && screened && C.gamOut) {  // (the screening formed only the candidates exactly: all of them now)
+#pragma unroll
+        for (int m = 0; m < NCH; ++m) gam[m] = S.hq[m];
+        gamma_dot_stream<SL, 2, true>(C, L, R, K, W, alpha, alRow, raLane, gam, S.Sp);
+    }
     if (C.gamOut) {
 #pragma unroll
         for (int m = 0; m < NCH; ++m) {
@@ -2648,6 +2827,37 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     if (NSL > 2) {  // the factor's global part starts all zero and stays zero outside the factor (ring_issue_faccol)
         for (int e = lane; e < 256 * 192; e += 64) L.F.L1[e] = 0.0;
         for (int e = lane; e < 192 * LR_STRIDE; e += 64) L.F.LR[e] = 0.0;
+    }
+    C.V32 = nullptr;
+    C.vmax = 0.0;
+    C.nScreen = 0; C.nCand = 0;
+    if (NSL > 2 && N <= 256 && (N & 3) == 0 && N >= 8) {
+        // V rounded to fp32 for the screening of the multiplier pass (gamma32_screen): one read of V per QP (about two
+        // passes' worth of bytes against ~140 passes), four columns' loads in flight; max |V_ij| on the way
+        float *v32 = reinterpret_cast<float *>(gscr + WAVE_LS_DOUBLES_BIG + 256 * 192 + 64 + 192 * LR_STRIDE + 64);
+        double vm = 0.0;
+        for (int c0 = 0; c0 < N; c0 += 4) {
+            double2 vv[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int r = 2 * lane + 128 * m;
+                    vv[u][m] = *reinterpret_cast<const double2 *>(C.V + (size_t)(c0 + u) * N + (r < N ? r : 0));
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int r = 2 * lane + 128 * m;
+                    if (r < N) {
+                        *reinterpret_cast<float2 *>(v32 + (size_t)(c0 + u) * N + r) = make_float2((float)vv[u][m].x, (float)vv[u][m].y);
+                        vm = fmax(vm, fmax(fabs(vv[u][m].x), fabs(vv[u][m].y)));
+                    }
+                }
+        }
+        C.vmax = wave_max(vm);
+        C.V32 = v32;
     }
     for (int e = lane; e < NR * NR; e += 64) L.H[e] = 0.0;
     for (int e = lane; e < MJX * MJX; e += 64) L.GG[e] = 0.0;
@@ -3097,7 +3307,8 @@ int wave_lds_bytes_big() {  // big-factor build: the same without LDS rows >= 64
 size_t wave_scratch_doubles(int variant) {
     // least-squares scratch, then (eight-per-CU build) rows 64..127 of up to 128 columns of the factor and the parked
     // second row slot; (big-factor build) rows 64..255 of up to 256 columns
-    if (variant == 2) return (size_t)WAVE_LS_DOUBLES_BIG + 256 * 192 + 64 + 192 * LR_STRIDE + 64;
+    // ... and V rounded to fp32 (N <= 256: 256 x 256 floats) plus one DMA piece of slack behind it
+    if (variant == 2) return (size_t)WAVE_LS_DOUBLES_BIG + 256 * 192 + 64 + 192 * LR_STRIDE + 64 + 256 * 256 / 2 + 256;
     return (size_t)WAVE_LS_DOUBLES + 128 * 64 + PARK_FIELDS * 64 + 64;
 }
 hipError_t launch_solve_wave(const SolveParams &P, int grid, int variant, hipStream_t stream) {
