@@ -1936,10 +1936,12 @@ __device__ __forceinline__ void gamma_dot_stream(const WCtx &C, const WLds &L, c
 template <int SL>
 __device__ __forceinline__ unsigned gamma32_screen(WCtx &C, const WLds &L, const Rows &R, int Kin, const double (&alpha)[NSL],
                                                    const double2 (&gam)[NCH], unsigned Sp, double tolG, int &ncand) {
-    constexpr int D = 8;            // ring slots of 1 KiB (one fp32 column each); the upper half of the ring is scratch
+    // ring slots of 1 KiB (one fp32 column each): all sixteen, twelve columns in flight -- a wavefront's share of the HBM rate
+    // is what it keeps in flight (with eight slots the halved bytes bought nothing: 4 KiB in flight per wavefront)
+    constexpr int D = 16;
     const int lane = lane_id();
     const int N = uni(C.N), K = uni(Kin);
-    float *scr = reinterpret_cast<float *>(const_cast<double *>(L.ring) + 1024);   // 8 KiB in: alpha32 (1 KiB), g32 (1 KiB)
+    float *scr = reinterpret_cast<float *>(const_cast<double *>(L.ring) + RING_BYTES / 8);   // behind the ring: alpha32 (1 KiB), g32 (1 KiB)
     float *g32L = scr + 256;
     // ---- alpha as a dense fp32 vector (piece layout: lane l holds elements 4 l .. 4 l + 3), sum |alpha|
     *reinterpret_cast<float4 *>(scr + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2009,22 +2011,33 @@ __device__ __forceinline__ unsigned gamma32_screen(WCtx &C, const WLds &L, const
 #pragma unroll
                 for (int u = 0; u < 4; ++u) issue((4 * g + u) % D, colof(4 * (g + DB) + u));
             }
-            // four wavefront sums: two halving steps, then the in-row and cross-row steps on one value per lane class
+            // four wavefront sums without an LDS round trip in the chain: two halving steps (lane pairs, then quads: a lane
+            // keeps ONE column's partial sum, class (b0, b1) = column 2 b0 + b1), the in-row steps, then the row broadcasts that
+            // are added up through v_readlane; lane 0 stores the totals by variable id
             const bool b0 = lane & 1, b1 = lane & 2;
-            float r0 = (b0 ? prod[2] : prod[0]) + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b0 ? prod[0] : prod[2]), DPP_XOR1, 0xF, 0xF, false));
-            float r1 = (b0 ? prod[3] : prod[1]) + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b0 ? prod[1] : prod[3]), DPP_XOR1, 0xF, 0xF, false));
-            float q = (b1 ? r1 : r0) + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b1 ? r0 : r1), DPP_XOR2, 0xF, 0xF, false));
-            q += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q), 0x124, 0xF, 0xF, false));  // row_ror:4
-            q += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, q), 0x128, 0xF, 0xF, false));  // row_ror:8
-            q += __builtin_bit_cast(float, bperm_i(__builtin_bit_cast(int, q), lane ^ 16));
-            q += __builtin_bit_cast(float, bperm_i(__builtin_bit_cast(int, q), lane ^ 32));
-            // (class (b0, b1) holds the sum of column u = 2 b0 + b1: lanes 0 .. 3 write the four sums; the variable's id is
-            //  fetched per lane -- its list position differs between the classes -- with every lane active)
-            {
-                const int e = 4 * g + 2 * (lane & 1) + ((lane >> 1) & 1);
-                const int ia = bperm_i(bv[0], e & 63), ib = bperm_i(bv[1], e & 63), ic = bperm_i(bv[2], e & 63);
-                const int vid = e < 64 ? ia : (e < 128 ? ib : ic);
-                if (lane < 4 && e < nb) g32L[vid & 255] = q;
+            auto fdpp = [](float x, auto ctrl) __attribute__((always_inline)) {
+                return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, false));
+            };
+            float r0 = (b0 ? prod[2] : prod[0]) + fdpp(b0 ? prod[0] : prod[2], IC<DPP_XOR1>{});
+            float r1 = (b0 ? prod[3] : prod[1]) + fdpp(b0 ? prod[1] : prod[3], IC<DPP_XOR1>{});
+            float q = (b1 ? r1 : r0) + fdpp(b1 ? r0 : r1, IC<DPP_XOR2>{});
+            q += fdpp(q, IC<0x124>{});  // row_ror:4
+            q += fdpp(q, IC<0x128>{});  // row_ror:8   (every lane of a class now holds its row's sum)
+            // (a row broadcast takes ONE lane of the previous row -- fine for a single sum, not for four classes: the four rows
+            //  are combined by v_readlane, four rows x four classes, on the scalar side)
+            float tot[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cl = ((u >> 1) & 1) | ((u & 1) << 1);   // the lane (within a quad) of class (b0, b1) = (u >> 1, u & 1)
+                float t = 0.f;
+#pragma unroll
+                for (int row = 0; row < 4; ++row) t += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q), 16 * row + cl));
+                tot[u] = t;
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (4 * g + u < nb) g32L[list_get(bv, 4 * g + u) & 255] = tot[u];
             }
         }
     }
@@ -2325,8 +2338,10 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
     if (NSL > 2 && SL >= 2 && C.V32 != nullptr) {
         // rows of [A;G] first (exact), then the fp32 screening of the bound columns, then the few exact columns it asks for
         gamma_stream<SL, 2>(C, L, R, 0, W, alpha, alRow, raLane, gam);
+        WPH(7);   // (rows of [A;G])
         int ncand = 0;
         const unsigned cm = gamma32_screen<SL>(C, L, R, K, alpha, gam, S.Sp, tolG, ncand);
+        WPH(15);  // fp32 screening of the bound columns
         if (ncand >= 0) {
             screened = true;
             candMask = cm;
@@ -3302,7 +3317,7 @@ int wave_lds_bytes(int rc) {  // rc <= 0: the builds that keep rows >= 64 in glo
     return dbl * 8;
 }
 int wave_lds_bytes_big() {  // big-factor build: the same without LDS rows >= 64, plus the column ring (1 KiB aligned)
-    return (wave_lds_bytes(0) + 1023) / 1024 * 1024 + RING_BYTES;
+    return (wave_lds_bytes(0) + 1023) / 1024 * 1024 + RING_BYTES + 2048;   // (+ 2 KiB: the screening pass's dense fp32 vectors)
 }
 size_t wave_scratch_doubles(int variant) {
     // least-squares scratch, then (eight-per-CU build) rows 64..127 of up to 128 columns of the factor and the parked

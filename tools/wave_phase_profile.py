@@ -27,10 +27,11 @@ lib.ssqp_debug_wave_phases(out, 1)
 names = ["rank filter", "Schur gather + lambda", "v + back substitution", "p, norm, accounting", "aStep ratios + min",
          "blocked: switches + bound shifts", "full step bookkeeping", "gamma pass", "KKT scan", "release + bound shift",
          "deletes (update, downdate, compaction, shifts)", "border sweep + H col after deletes", "c refresh before append",
-         "one append (row, border row, H)", "  of which: gather V[F,j] + forward sweep + row stores"]
+         "one append (row, border row, H)", "  of which: gather V[F,j] + forward sweep + row stores",
+         "fp32 screening of the bound columns (big-factor build; 'gamma pass' is then the rows + the exact candidates)"]
 iters = int(res["status"].sum())
 ms = db.ctx.last_kernel_ms()
-tot = sum(out[:14])  # (slot 14 lies inside slot 13)
+tot = sum(out[:14]) + out[15]  # (slot 14 lies inside slot 13)
 print("cycles per pass, whole QP lifetime / passes: %.0f" % (out[31] / iters))
 print("config", name, "nprob", nprob, "total passes", iters, "kernel ms (diagnostic build)", ms)
 print("stamped cycles per pass: %.0f" % (tot / iters))
