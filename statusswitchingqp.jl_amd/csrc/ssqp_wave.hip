@@ -1936,9 +1936,6 @@ __device__ __forceinline__ void gamma_dot_stream(const WCtx &C, const WLds &L, c
 template <int SL>
 __device__ __forceinline__ unsigned gamma32_screen(WCtx &C, const WLds &L, const Rows &R, int Kin, const double (&alpha)[NSL],
                                                    const double2 (&gam)[NCH], unsigned Sp, double tolG, int &ncand) {
-    // ring slots of 1 KiB (one fp32 column each): all sixteen, twelve columns in flight -- a wavefront's share of the HBM rate
-    // is what it keeps in flight (with eight slots the halved bytes bought nothing: 4 KiB in flight per wavefront)
-    constexpr int D = 16;
     const int lane = lane_id();
     const int N = uni(C.N), K = uni(Kin);
     float *scr = reinterpret_cast<float *>(const_cast<double *>(L.ring) + RING_BYTES / 8);   // behind the ring: alpha32 (1 KiB), g32 (1 KiB)
@@ -1983,48 +1980,37 @@ __device__ __forceinline__ unsigned gamma32_screen(WCtx &C, const WLds &L, const
             const int e = lane + 64 * h;
             bv[h] = blist[e < nb ? e : nb - 1];
         }
-        auto colof = [&](int e) -> const double * {   // (as a double pointer for the DMA helper: N floats = N / 2 doubles)
-            return reinterpret_cast<const double *>(C.V32 + (size_t)list_get(bv, e < nb ? e : nb - 1) * N);
-        };
-        const unsigned vo = (unsigned)(4 * lane < N ? 4 * lane : 0) * 4u;   // this lane's 16 bytes of a column
-        auto issue = [&](int slot, const double *col) {
-            glds16_s(uni_ptr(col), vo, L.ringAddr + (unsigned)slot * 1024u);
-        };
-        constexpr int DB = D / 4;
-        for (int g = 0; g < DB && g < ngrp; ++g)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) issue((4 * g + u) % D, colof(4 * g + u));
-        wait_all_landed();
+        // The columns come straight into REGISTERS (one 16-byte load per lane and column), three groups of four in flight in
+        // three register sets that change roles: an LDS-DMA piece costs 100+ cycles to issue and its data another LDS read,
+        // which is what bounded this loop at ~400 cycles per column whatever the column's size
         const bool in = 4 * lane < N;   // (N a multiple of 4)
-        for (int g = 0; g < ngrp; ++g) {
-            if (g + DB <= ngrp) wait_vm<D - 4>();  // (DB - 1 younger groups are in flight)
-            else wait_vm<0>();
+        const float *vbase = C.V32 + (in ? 4 * lane : 0);
+        auto load4 = [&](int g, float4 (&v)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = 4 * g + u;
+                v[u] = *reinterpret_cast<const float4 *>(vbase + (size_t)list_get(bv, e < nb ? e : nb - 1) * N);
+            }
+        };
+        auto use4 = [&](int g, const float4 (&v)[4]) __attribute__((always_inline)) {
             float prod[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(L.ring) + ((4 * g + u) % D) * 256 + 4 * lane);
-                const float sacc = fmaf(v.w, ad.w, fmaf(v.z, ad.z, fmaf(v.y, ad.y, v.x * ad.x)));
+                const float sacc = fmaf(v[u].w, ad.w, fmaf(v[u].z, ad.z, fmaf(v[u].y, ad.y, v[u].x * ad.x)));
                 prod[u] = in ? sacc : 0.f;
             }
-            wait_lds();
-            if (g + DB < ngrp) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) issue((4 * g + u) % D, colof(4 * (g + DB) + u));
-            }
             // four wavefront sums without an LDS round trip in the chain: two halving steps (lane pairs, then quads: a lane
-            // keeps ONE column's partial sum, class (b0, b1) = column 2 b0 + b1), the in-row steps, then the row broadcasts that
-            // are added up through v_readlane; lane 0 stores the totals by variable id
+            // keeps ONE column's partial sum, class (b0, b1) = column 2 b0 + b1), the in-row steps, then the four rows are
+            // added up through v_readlane; lane 0 stores the totals by variable id
             const bool b0 = lane & 1, b1 = lane & 2;
             auto fdpp = [](float x, auto ctrl) __attribute__((always_inline)) {
                 return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, false));
             };
-            float r0 = (b0 ? prod[2] : prod[0]) + fdpp(b0 ? prod[0] : prod[2], IC<DPP_XOR1>{});
-            float r1 = (b0 ? prod[3] : prod[1]) + fdpp(b0 ? prod[1] : prod[3], IC<DPP_XOR1>{});
+            const float r0 = (b0 ? prod[2] : prod[0]) + fdpp(b0 ? prod[0] : prod[2], IC<DPP_XOR1>{});
+            const float r1 = (b0 ? prod[3] : prod[1]) + fdpp(b0 ? prod[1] : prod[3], IC<DPP_XOR1>{});
             float q = (b1 ? r1 : r0) + fdpp(b1 ? r0 : r1, IC<DPP_XOR2>{});
             q += fdpp(q, IC<0x124>{});  // row_ror:4
             q += fdpp(q, IC<0x128>{});  // row_ror:8   (every lane of a class now holds its row's sum)
-            // (a row broadcast takes ONE lane of the previous row -- fine for a single sum, not for four classes: the four rows
-            //  are combined by v_readlane, four rows x four classes, on the scalar side)
             float tot[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -2039,6 +2025,18 @@ __device__ __forceinline__ unsigned gamma32_screen(WCtx &C, const WLds &L, const
                 for (int u = 0; u < 4; ++u)
                     if (4 * g + u < nb) g32L[list_get(bv, 4 * g + u) & 255] = tot[u];
             }
+        };
+        float4 va[4], vb[4], vc[4];
+        load4(0, va);
+        load4(1, vb);
+        load4(2, vc);
+        for (int g = 0; g < ngrp; g += 3) {  // (groups beyond the list repeat its last column: their sums are dropped)
+            use4(g, va);
+            load4(g + 3, va);
+            if (g + 1 < ngrp) use4(g + 1, vb);
+            load4(g + 4, vb);
+            if (g + 2 < ngrp) use4(g + 2, vc);
+            load4(g + 5, vc);
         }
     }
     wave_sync();
