@@ -372,11 +372,26 @@ def run(args):
                 set_mode("lanes")
 
                 def e2e_steps(n):
-                    for i in range(n):
-                        ln = lanes[i % nlanes]
-                        with torch.cuda.stream(ln.stream):
-                            ln.batch.phase1()
-                            ln.batch.solve()
+                    # A round = one step per lane.  The Phase-1 kernel keeps a QP's whole LP in 512 registers per lane: one
+                    # wavefront per SIMD and nothing beside it, so a Phase-1 launch that trickles in between another lane's
+                    # loop wavefronts (two per SIMD) stalls both.  The round's Phase-1 launches therefore go out together, on
+                    # their lanes' streams, and the round's loops start once all of them are done (events): Phase-1 fills the
+                    # SIMDs the previous round's loops drain, then the loops share the chip among themselves as in the timed
+                    # region.
+                    for r0 in range(0, n, nlanes):
+                        rl = [lanes[i % nlanes] for i in range(r0, min(n, r0 + nlanes))]
+                        evs = []
+                        for ln in rl:
+                            with torch.cuda.stream(ln.stream):
+                                ln.batch.phase1()
+                                e = torch.cuda.Event()
+                                e.record()
+                                evs.append(e)
+                        for ln in rl:
+                            with torch.cuda.stream(ln.stream):
+                                for e in evs:
+                                    ln.stream.wait_event(e)
+                                ln.batch.solve()
                     for ln in lanes:
                         ln.ctx.sync(ln.stream.cuda_stream)
                     torch.cuda.synchronize(dev)

@@ -485,7 +485,7 @@ static int solve_dev_impl(ssqp_ctx *c, int nprob, int N, int M, int J, const dou
             if (!hip_ok(c, ssqp::launch_phase1(nprob, N, M, J, dA, dG, db, dg, dd, du, settingsLP->tol, (double *)c->fullX0.p, dS,
                                                (int32_t *)c->fullSt.p, (double *)c->p1ws.p, ssqp::phase1_ws_doubles(N, M, J),
                                                (int *)c->p1wsInt.p, ssqp::phase1_ws_ints(N, M, J),
-                                               (const unsigned int *)c->p1queue.p, (const int *)c->p1list.p, 2 * c->numCU, &ho, s),
+                                               (const unsigned int *)c->p1queue.p, (const int *)c->p1list.p, 64, &ho, s),
                         "phase-1 launch")) return SSQP_ERR_HIP;
         } else if (bigFirst) {
             if (!hip_ok(c, ssqp::launch_solve_wave(B, bigGrid, 2, s), "big-factor wave launch")) return SSQP_ERR_HIP;
@@ -827,7 +827,7 @@ int ssqp_phase1_batch_dev_f64(ssqp_ctx *c, int nprob, int N, int M, int J, const
     // (the workspaces are indexed by problem id: a listed QP may be any of them)
     if (!ensure(c, c->p1ws, (size_t)nprob * wd * 8) || !ensure(c, c->p1wsInt, (size_t)nprob * wi * 4)) return SSQP_ERR_ALLOC;
     return hip_ok(c, ssqp::launch_phase1(nprob, N, M, J, dA, dG, db, dg, dd, du, st->tol, dx0, dS, dstatus,
-                                         (double *)c->p1ws.p, wd, (int *)c->p1wsInt.p, wi, listCount, list, 2 * c->numCU, nullptr, s),
+                                         (double *)c->p1ws.p, wd, (int *)c->p1wsInt.p, wi, listCount, list, list ? 64 : 0, nullptr, s),
                   "phase-1 launch") ? SSQP_OK : SSQP_ERR_HIP;
 }
 

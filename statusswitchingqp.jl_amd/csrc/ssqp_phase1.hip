@@ -641,22 +641,31 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                             for (int u = 0; u < CG; ++u) sacc[v][u] = 0.0;
                         // (the LP's entries of step t + 1 are requested before step t's products are formed: with one
                         //  workgroup on the chip nobody else hides the L2 round trip)
-                        double at[CG], an[CG];
+                        double at[CG], a1[CG], an[CG], iv[RG], ivn[RG];
 #pragma unroll
-                        for (int u = 0; u < CG; ++u) at[u] = A1[kc[u]];
-                        for (int t = 0; t < M0; ++t) {
-                            const int tn = t + 1 < M0 ? t + 1 : t;
+                        for (int u = 0; u < CG; ++u) {
+                            at[u] = A1[kc[u]];
+                            a1[u] = A1[(size_t)(M0 > 1 ? 1 : 0) * N1 + kc[u]];
+                        }
 #pragma unroll
-                            for (int u = 0; u < CG; ++u) an[u] = A1[(size_t)tn * N1 + kc[u]];
-                            double iv[RG];
+                        for (int v = 0; v < RG; ++v) iv[v] = invB[rr[v]];
+                        for (int t = 0; t < M0; ++t) {  // (the LP's entries two steps ahead, the row of inv(B) one step ahead)
+                            const int t2 = t + 2 < M0 ? t + 2 : M0 - 1, t1 = t + 1 < M0 ? t + 1 : t;
 #pragma unroll
-                            for (int v = 0; v < RG; ++v) iv[v] = invB[(size_t)t * M0 + rr[v]];
+                            for (int u = 0; u < CG; ++u) an[u] = A1[(size_t)t2 * N1 + kc[u]];
+#pragma unroll
+                            for (int v = 0; v < RG; ++v) ivn[v] = invB[(size_t)t1 * M0 + rr[v]];
 #pragma unroll
                             for (int v = 0; v < RG; ++v)
 #pragma unroll
                                 for (int u = 0; u < CG; ++u) sacc[v][u] += iv[v] * at[u];
 #pragma unroll
-                            for (int u = 0; u < CG; ++u) at[u] = an[u];
+                            for (int u = 0; u < CG; ++u) {
+                                at[u] = a1[u];
+                                a1[u] = an[u];
+                            }
+#pragma unroll
+                            for (int v = 0; v < RG; ++v) iv[v] = ivn[v];
                         }
 #pragma unroll
                         for (int v = 0; v < RG; ++v)
@@ -1093,7 +1102,9 @@ hipError_t launch_phase1(int nprob, int N, int M, int J, const double *A, const 
     // four workgroups per CU keep 1,024 QPs resident: the N1-vectors go to LDS when they fit in a quarter of it
     size_t lds = phase1_lds_bytes(M, J);
     P.ldsVec = 0;
-    if (phase1_lds_bytes_vec(N, M, J) <= (size_t)LDS_BYTES / 4) {
+    // (on a list -- what the wavefront kernel left, usually nothing -- the launch stays small in every respect: a few
+    //  blocks with the small LDS image find room on a busy chip at once instead of queueing behind another lane's kernels)
+    if (!list && phase1_lds_bytes_vec(N, M, J) <= (size_t)LDS_BYTES / 4) {
         P.ldsVec = 1;
         lds = phase1_lds_bytes_vec(N, M, J);
     }

@@ -8,6 +8,9 @@ run cfg3 --config cfg3 --nprob 1024 --steps 6 --warmup 2 --cpu-seconds 6 --pmc-j
 run cfg4 --config cfg4 --nprob 1024 --steps 20 --warmup 3 --cpu-seconds 8
 run cfg4_serial --config cfg4 --nprob 1024 --steps 6 --warmup 1 --streams 1 --no-cpu --skip-dense
 run cfg5 --config cfg5 --nprob 1 --steps 3 --warmup 1 --cpu-seconds 3
+# BASELINE config 4 whole on ONE GPU (8,192 QPs, 16 GiB of V per batch): the strong-scaling anchor; one lane and the default
+run cfg4_8192_serial --config cfg4 --nprob 8192 --steps 3 --warmup 1 --streams 1 --no-cpu --skip-dense --repeats 3
+run cfg4_8192 --config cfg4 --nprob 8192 --steps 4 --warmup 2 --streams 2 --no-cpu --skip-dense --repeats 3
 python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob("gpurun_out/configs/*.json")):

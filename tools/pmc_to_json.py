@@ -57,8 +57,17 @@ if f3 is not None and w3 is not None:
     res3 = {"config": "cfg3", "nprob": 1024, "tag": tag, "kernel_source_sha256": bench.kernel_source_hash(),
             "correction": res["correction"],
             "default_formulation": {"FETCH_SIZE_KiB": f3, "WRITE_SIZE_KiB": w3, "hbm_bytes_per_launch": (2.0 * f3 + w3) * 1024.0,
-                                    "sq": per_launch("pmc_sq1_cfg3")}}
+                                    "sq": {**per_launch("pmc_sq1_cfg3"), **per_launch("pmc_sq3_cfg3")}}}
     json.dump(res3, open(os.path.join(base, "pmc_counters_cfg3.json"), "w"), indent=1)
     print(json.dumps(res3, indent=1))
+# the large-K path (blocked LDL' with f64 MFMA tiles) on the K -> 320 workload: MFMA counters of the workgroup kernel
+mf = per_launch("pmc_mfma_k320", "ssqp_solve_kernel")
+if mf:
+    log = open(os.path.join(base, "mfma_k320.log")).read() if os.path.exists(os.path.join(base, "mfma_k320.log")) else ""
+    json.dump({"workload": "gen:320,1,4,640,0.5,0.0,1.0,0.0 x 256 QPs, wave_kernel=0", "tag": tag,
+               "kernel_source_sha256": bench.kernel_source_hash(), "counters_per_launch": mf,
+               "mfma_busy_over_cu_busy": mf.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(mf.get("SQ_BUSY_CU_CYCLES", 1), 1),
+               "debug_parity_line": [l for l in log.splitlines() if l.startswith("gen:")][-1:]},
+              open(os.path.join(base, "pmc_mfma_k320.json"), "w"), indent=1)
 json.dump(res, open(os.path.join(base, "pmc_counters.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))

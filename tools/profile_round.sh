@@ -31,5 +31,10 @@ run trace_cfg3    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t
 run fetch_cfg3    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_cfg3 -- $C3 --steps 1 --warmup 0
 run write_cfg3    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_cfg3 -- $C3 --steps 1 --warmup 0
 run sq1_cfg3      rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc_sq1_cfg3 -- $C3 --steps 1 --warmup 0
+# ... its instruction cache (a 190 k-instruction kernel against a 64 KiB cache) and vector-memory instruction mix
+run sq3_cfg3      rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_MISSES SQC_ICACHE_HITS SQ_INSTS_BRANCH SQ_BUSY_CYCLES SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $OUT/pmc_sq3_cfg3 -- $C3 --steps 1 --warmup 0
+# the large-K (blocked LDL', f64 MFMA) path of the workgroup kernel: K -> 320 rows, 256 QPs (no BASELINE config reaches it)
+K320="python3 $GRAFT_REPO_ROOT/tools/debug_parity.py gen:320,1,4,640,0.5,0.0,1.0,0.0 256 wave_kernel=0"
+run mfma_k320     rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_mfma_k320 -- $K320
 python3 $GRAFT_REPO_ROOT/tools/pmc_to_json.py $TAG
 find $OUT -name "*kernel_stats.csv"
