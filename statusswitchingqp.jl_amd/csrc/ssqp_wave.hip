@@ -31,6 +31,17 @@
 #include "ssqp_phase1_wave.h"   // (the single-launch solveQP(Q): Phase-1 in front of the loop, SSQP_WAVE_VARIANT 0 only)
 #endif
 
+// -DSSQP_WAVE_LEAN: the builds for launches that ask for neither statistics nor a trace (both optional pointers of the
+// boundary): the byte / flop accounting and the per-pass trace records are not compiled in -- fewer live scalars in a
+// kernel that spills hundreds of them.  Same decisions, same results; the API picks the build by the pointers it is given.
+#ifdef SSQP_WAVE_LEAN
+#define ACCT(stmt) do { } while (0)
+#define SSQP_LEAN_BUILD 1
+#else
+#define ACCT(stmt) do { stmt; } while (0)
+#define SSQP_LEAN_BUILD 0
+#endif
+
 namespace ssqp {
 
 // ---- diagnostic build only (-DSSQP_PHASE_PROFILE): cycles per phase of the wavefront kernel ----
@@ -1539,9 +1550,9 @@ __device__ __forceinline__ bool append_var(WCtx &C, const WLds &L, Rows &R, int 
     h_rank1(L, rdn);
     gg_rank1(L, 1.0);
     wave_sync();
-    C.sRead += 64ll * K + 64ll * MJ + 16;
+    ACCT(C.sRead += 64ll * K + 64ll * MJ + 16);
     if (NSL > 2 && SL >= 2 && K > 64)
-        C.sRead += 8ll * ((long long)(K - 64) * 64 + (long long)(K - 64) * (K - 65) / 2);
+        ACCT(C.sRead += 8ll * ((long long)(K - 64) * 64 + (long long)(K - 64) * (K - 65) / 2));
     K += 1;
     return true;
 }
@@ -1707,7 +1718,7 @@ __device__ __forceinline__ void refresh_caches(WCtx &C, double2 (&hq)[NCH], doub
         zb[m].x = (r < N && st_of(Sp, 2 * m) != SSQP_IN) ? zx : 0.0;
         zb[m].y = (r < N && st_of(Sp, 2 * m + 1) != SSQP_IN) ? zy : 0.0;
     }
-    int ncol = 0;
+    [[maybe_unused]] int ncol = 0;
 #pragma unroll
     for (int m = 0; m < NCH; ++m) {
         unsigned long long mx = __ballot(zb[m].x != 0.0), my = __ballot(zb[m].y != 0.0);
@@ -1740,7 +1751,7 @@ __device__ __forceinline__ void refresh_caches(WCtx &C, double2 (&hq)[NCH], doub
         be = (lane == w) ? b : be;
     }
     bEv = be;
-    C.sRead += 8ll * N * (ncol + MJ + 1);
+    ACCT(C.sRead += 8ll * N * (ncol + MJ + 1));
 }
 
 // The per-QP state that lives across passes
@@ -2073,7 +2084,7 @@ __device__ __forceinline__ unsigned gamma32_screen(WCtx &C, const WLds &L, const
         cm |= c ? 1u << k : 0u;
         nc += __popcll(__ballot(c));
     }
-    C.sRead += 4ll * N * nb;
+    ACCT(C.sRead += 4ll * N * nb);
     C.nScreen += 1;
     ncand = nc > 48 ? -1 : nc;
     return cm;
@@ -2083,7 +2094,8 @@ __device__ __forceinline__ unsigned gamma32_screen(WCtx &C, const WLds &L, const
 template <int SL>
 __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, double *__restrict__ gscr) {
     const int lane = lane_id();
-    const int N = C.N, M = C.M, J = C.J, MJ = C.MJ;
+    [[maybe_unused]] const int J = C.J;
+    const int N = C.N, M = C.M, MJ = C.MJ;
     const double tol = C.tol, tolG = C.tolG;
     Rows &R = S.R;
     const int K = S.K;
@@ -2167,7 +2179,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
         if (K <= 128) back_sweep_rows<SL, 1>(L, K, v);
         else back_sweep_rows<SL, 2>(L, K, v);
         // (the factor's global part, rows max(64, c + 1) .. K - 1 of every column: read once here, once by the append)
-        if (K > 64) C.sRead += 8ll * ((long long)(K - 64) * 64 + (long long)(K - 64) * (K - 65) / 2);
+        if (K > 64) ACCT(C.sRead += 8ll * ((long long)(K - 64) * 64 + (long long)(K - 64) * (K - 65) / 2));
     } else {
         back_sweep<SL>(L.F, K, v);
     }
@@ -2189,10 +2201,10 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
     const bool anyNan = __ballot(pnan) != 0ull;
 
     {   // per-pass accounting
-        const long long k = K, r = N - K, w = W;
-        C.sBytes += 8ll * (k * k + r * k) + 8ll * MJ * N + 48ll * N + 4ll * (N + J);
-        C.sFlops += k * k * k + 4 * k * k * w + 2 * k * k + 2 * r * k + 2ll * W0 * r + w * w * w;
-        C.sK3 += k * k * k;
+        [[maybe_unused]] const long long k = K, r = N - K, w = W;
+        ACCT(C.sBytes += 8ll * (k * k + r * k) + 8ll * MJ * N + 48ll * N + 4ll * (N + J));
+        ACCT(C.sFlops += k * k * k + 4 * k * k * w + 2 * k * k + 2 * r * k + 2ll * W0 * r + w * w * w);
+        ACCT(C.sK3 += k * k * k);
     }
 
     WPH(3);  // p, norm, accounting
@@ -2232,7 +2244,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
         const double lin = (inact && po > tol) ? zo / po : INF;  // :85-86  (lane M + j: inequality j)
         lmin = fmin(lmin, lin);
         const double L1 = wave_min(lmin);
-        C.sFlops += 2ll * (J - __popc(S.Emask)) * (N + K);
+        ACCT(C.sFlops += 2ll * (J - __popc(S.Emask)) * (N + K));
         WPH(4);  // aStep ratios + min
         if (L1 < 1.0) {  // blocked  (:98-127)
             int firstId = 0x7fffffff;
@@ -2291,7 +2303,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
                         S.nShift += 1;
                         S.blkDz = zn;  // (used only when this is the pass's single deletion)
                         S.cDirty = true;
-                        C.sRead += 8ll * N + 64ll * MJ;
+                        ACCT(C.sRead += 8ll * N + 64ll * MJ);
                     }
                 }
             }
@@ -2350,21 +2362,21 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
                 gamma_dot_stream<SL, 2, false>(C, L, R, K, W, alpha, alRow, raLane, gam, spc);
             }
             C.nCand += ncand;
-            C.sRead += 8ll * N * (ncand + W);
+            ACCT(C.sRead += 8ll * N * (ncand + W));
         } else {
             gamma_dot_stream<SL, 2, false>(C, L, R, K, W, alpha, alRow, raLane, gam, S.Sp);   // (every bound column, exactly)
-            C.sRead += 8ll * N * (N - K + W);
+            ACCT(C.sRead += 8ll * N * (N - K + W));
         }
     } else if (NSL > 2) {  // (big-factor build: the list below streamed through the LDS ring)
         if (SL >= 2 && N <= 256 && 2 * K > N) {  // fewer bound than free variables: by the bound columns (V is symmetric)
             if (N <= 128) gamma_dot_stream<SL, 1>(C, L, R, K, W, alpha, alRow, raLane, gam, S.Sp);
             else gamma_dot_stream<SL, 2>(C, L, R, K, W, alpha, alRow, raLane, gam, S.Sp);
-            C.sRead += 8ll * N * (N - K + W);
+            ACCT(C.sRead += 8ll * N * (N - K + W));
         } else {
             if (N <= 128) gamma_stream<SL, 1>(C, L, R, K, W, alpha, alRow, raLane, gam);
             else if (N <= 256) gamma_stream<SL, 2>(C, L, R, K, W, alpha, alRow, raLane, gam);
             else gamma_stream<SL, 4>(C, L, R, K, W, alpha, alRow, raLane, gam);
-            C.sRead += 8ll * N * (K + W);
+            ACCT(C.sRead += 8ll * N * (K + W));
         }
     } else {
         // one list: the K free columns of V (weights alpha) and the W kept rows of [A;G] (weights alphaL), NB at a
@@ -2403,12 +2415,12 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
                 }
             }
         }
-        C.sRead += 8ll * N * (K + W);
+        ACCT(C.sRead += 8ll * N * (K + W));
     }
     {
-        const long long r = N - K;
-        C.sBytes += 8ll * r * r;
-        C.sFlops += 2ll * r * r + 2ll * r * K;
+        [[maybe_unused]] const long long r = N - K;
+        ACCT(C.sBytes += 8ll * r * r);
+        ACCT(C.sFlops += 2ll * r * r + 2ll * r * K);
     }
 
     WPH(7);  // gamma pass
@@ -2525,7 +2537,7 @@ __device__ __forceinline__ int wave_pass(WCtx &C, const WLds &L, WState &S, doub
                 S.nShift += 1;
                 S.cDirty = true;
                 S.relDz = -zr;
-                C.sRead += 8ll * N + 64ll * MJ;
+                ACCT(C.sRead += 8ll * N + 64ll * MJ);
             }
             S.appJ = jv;
         } else {
@@ -2778,7 +2790,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     C.q = P.q + (size_t)prob * P.sq;
     C.dlo = P.d + (size_t)prob * P.sd;
     C.uhi = P.u + (size_t)prob * P.su;
-    C.trace = P.trace ? P.trace + (size_t)prob * P.ntrace : nullptr;
+    C.trace = (!SSQP_LEAN_BUILD && P.trace) ? P.trace + (size_t)prob * P.ntrace : nullptr;
     C.ntrace = P.ntrace;
     C.lamOut = P.lamOut ? P.lamOut + (size_t)prob * MJ : nullptr;
     C.gamOut = P.gamOut ? P.gamOut + (size_t)prob * N : nullptr;
@@ -2875,7 +2887,7 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
     for (int e = lane; e < NR * NR; e += 64) L.H[e] = 0.0;
     for (int e = lane; e < MJX * MJX; e += 64) L.GG[e] = 0.0;
     wave_sync();
-    C.sRead += 8ll * N + 4ll * (N + J);
+    ACCT(C.sRead += 8ll * N + 4ll * (N + J));
 
     bool handover = false;
     for (;;) {
@@ -2949,8 +2961,8 @@ __device__ __forceinline__ void wave_solve_one(const SolveParams &P, int prob, c
                         rel |= 1u << k;
                     }
                 }
-                C.sBytes += 8ll * N * N + 16ll * N + 4ll * (N + J);
-                C.sFlops += 2ll * N * N;
+                ACCT(C.sBytes += 8ll * N * N + 16ll * N + 4ll * (N + J));
+                ACCT(C.sFlops += 2ll * N * N);
                 const bool any = __ballot(flag) != 0ull;
                 bool done = !any;
                 if (any) {
@@ -3130,8 +3142,9 @@ __device__ __forceinline__ void wave_carve(const SolveParams &P, unsigned char *
 }
 
 #ifndef SSQP_FULL
-template <int WPS, bool PARK, int SLOTS>  // (SLOTS = NSL: part of the kernel's name, so that the builds' kernels differ)
+template <int WPS, bool PARK, int SLOTS, bool LEAN>  // (SLOTS = NSL, LEAN: part of the kernel's name, so that the builds' kernels differ)
 __global__ __launch_bounds__(64, WPS) void ssqp_wave_kernel(SolveParams P) {
+    static_assert(LEAN == (SSQP_LEAN_BUILD != 0), "one build per translation unit");
     static_assert(SLOTS == NSL, "one build per translation unit");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WLds L;
@@ -3266,18 +3279,25 @@ hipError_t launch_solve_full(const SolveParams &P, int grid, const double *A, co
 }
 }  // namespace ssqp
 #else
+#if SSQP_LEAN_BUILD
+#define WV_NAME(base) base##_lean
+#define WV_LEANARG true
+#else
+#define WV_NAME(base) base
+#define WV_LEANARG false
+#endif
 #if SSQP_WAVE_VARIANT == 0
-#define WV_KERNEL ssqp_wave_kernel<1, false, 2>
-#define WV_LAUNCH launch_wave_v0
-#define WV_PHASES wave_phases_v0
+#define WV_KERNEL ssqp_wave_kernel<1, false, 2, WV_LEANARG>
+#define WV_LAUNCH WV_NAME(launch_wave_v0)
+#define WV_PHASES WV_NAME(wave_phases_v0)
 #elif SSQP_WAVE_VARIANT == 1
-#define WV_KERNEL ssqp_wave_kernel<2, true, 2>
-#define WV_LAUNCH launch_wave_v1
-#define WV_PHASES wave_phases_v1
+#define WV_KERNEL ssqp_wave_kernel<2, true, 2, WV_LEANARG>
+#define WV_LAUNCH WV_NAME(launch_wave_v1)
+#define WV_PHASES WV_NAME(wave_phases_v1)
 #elif SSQP_WAVE_VARIANT == 2
-#define WV_KERNEL ssqp_wave_kernel<1, false, 4>
-#define WV_LAUNCH launch_wave_v2
-#define WV_PHASES wave_phases_v2
+#define WV_KERNEL ssqp_wave_kernel<1, false, 4, WV_LEANARG>
+#define WV_LAUNCH WV_NAME(launch_wave_v2)
+#define WV_PHASES WV_NAME(wave_phases_v2)
 #else
 #error "SSQP_WAVE_VARIANT: 0, 1 or 2"
 #endif
@@ -3302,9 +3322,12 @@ int WV_PHASES(unsigned long long *out64, int reset) {  // adds this build's stam
 }
 #endif
 
-#if SSQP_WAVE_VARIANT == 0
+#if SSQP_WAVE_VARIANT == 0 && !SSQP_LEAN_BUILD
 hipError_t launch_wave_v1(const SolveParams &P, int grid, hipStream_t stream);
 hipError_t launch_wave_v2(const SolveParams &P, int grid, hipStream_t stream);
+hipError_t launch_wave_v0_lean(const SolveParams &P, int grid, hipStream_t stream);
+hipError_t launch_wave_v1_lean(const SolveParams &P, int grid, hipStream_t stream);
+hipError_t launch_wave_v2_lean(const SolveParams &P, int grid, hipStream_t stream);
 bool wave_kernel_applies(int N, int M, int J) {
     return (N % 2 == 0) && N >= 2 && N <= WAVE_MAXN && (M + J) <= WAVE_MJ;
 }
@@ -3325,15 +3348,21 @@ size_t wave_scratch_doubles(int variant) {
     return (size_t)WAVE_LS_DOUBLES + 128 * 64 + PARK_FIELDS * 64 + 64;
 }
 hipError_t launch_solve_wave(const SolveParams &P, int grid, int variant, hipStream_t stream) {
+    // a launch that asks for neither statistics nor a trace gets the builds that do not carry them (-DSSQP_WAVE_LEAN)
+    if (!P.stats && !P.trace) {
+        if (variant == 2) return launch_wave_v2_lean(P, grid, stream);
+        if (variant == 1) return launch_wave_v1_lean(P, grid, stream);
+        return launch_wave_v0_lean(P, grid, stream);
+    }
     if (variant == 2) return launch_wave_v2(P, grid, stream);
     if (variant == 1) return launch_wave_v1(P, grid, stream);
     return launch_wave_v0(P, grid, stream);
 }
-#endif  // SSQP_WAVE_VARIANT == 0
+#endif  // SSQP_WAVE_VARIANT == 0 && !SSQP_LEAN_BUILD
 
 }  // namespace ssqp
 
-#if defined(SSQP_PHASE_PROFILE) && SSQP_WAVE_VARIANT == 0
+#if defined(SSQP_PHASE_PROFILE) && SSQP_WAVE_VARIANT == 0 && !SSQP_LEAN_BUILD
 namespace ssqp {
 int wave_phases_v1(unsigned long long *out64, int reset);
 int wave_phases_v2(unsigned long long *out64, int reset);

@@ -353,6 +353,7 @@ class DeviceBatch:
         self.ntrace = int(ntrace)
         self.trace = torch.zeros((self.P, max(self.ntrace, 1), 4), dtype=torch.int32, device=dev)
         self.lam = self.gam = None   # multiplier outputs (want_multipliers())
+        self.use_stats = True        # False: the launch asks for no statistics (and, with ntrace = 0, gets the lean kernel builds)
         torch.cuda.synchronize(dev)
 
     def want_multipliers(self):
@@ -386,6 +387,7 @@ class DeviceBatch:
         o.ntrace = self.ntrace
         o.trace = torch.zeros_like(self.trace)
         o.lam = o.gam = None
+        o.use_stats = self.use_stats
         torch.cuda.synchronize(self.S0.device)
         return o
 
@@ -419,7 +421,7 @@ class DeviceBatch:
         rc = _capi.lib().ssqp_solve_batch_strided_dev_f64(
             self.ctx.handle, self.P, self.N, self.M, self.J, *[self._ptr(t[k]) for k in "VAGqbgdu"], C.byref(strides),
             self._ptr(self.S), self._ptr(self.x0), self._ptr(self.z), C.byref(cs), self._ptr(self.status),
-            self._ptr(self.detail), self._ptr(self.stats), self._ptr(self.trace) if self.ntrace else None,
+            self._ptr(self.detail), self._ptr(self.stats) if self.use_stats else None, self._ptr(self.trace) if self.ntrace else None,
             self.ntrace, self._ptr(self.lam) if self.lam is not None else None,
             self._ptr(self.gam) if self.gam is not None else None, C.c_void_p(stream))
         _capi.check(rc, self.ctx.handle)
@@ -442,7 +444,7 @@ class DeviceBatch:
         rc = _capi.lib().ssqp_solve_full_batch_dev_f64(
             self.ctx.handle, self.P, self.N, self.M, self.J, *[self._ptr(t[k]) for k in "VAGqbgdu"],
             self._ptr(self.S), self._ptr(self.z), C.byref(cs), C.byref(csl), self._ptr(self.status),
-            self._ptr(self.detail), self._ptr(self.stats), self._ptr(self.lam) if self.lam is not None else None,
+            self._ptr(self.detail), self._ptr(self.stats) if self.use_stats else None, self._ptr(self.lam) if self.lam is not None else None,
             self._ptr(self.gam) if self.gam is not None else None, C.c_void_p(stream))
         _capi.check(rc, self.ctx.handle)
 

@@ -135,3 +135,26 @@ def test_single_launch_solveQP_refuses_what_it_is_not_built_for(pkg):
     db = pkg.DeviceBatch(prob, np.zeros((4, 64 + 12), dtype=np.int32), np.zeros((4, 64)))
     with pytest.raises(pkg.SSQPError):
         db.solve_full()
+
+
+@pytest.mark.parametrize("name,nprob,opts", [("cfg4", 128, dict()), ("cfg4", 128, dict(wave_qp_per_cu=8)), ("cfg3", 32, dict())])
+def test_lean_builds_without_statistics_give_the_same_results(pkg, orc, name, nprob, opts):
+    """a launch with stats = NULL and no trace runs the kernel builds that do not carry the byte / flop accounting
+    (-DSSQP_WAVE_LEAN): same z, S, status as the accounting builds and as the oracle -- all three builds of the chain"""
+    cfg = pkg.CONFIGS[name]
+    prob = pkg.generate_batch(cfg, nprob, 555)
+    x0, S0, st = pkg.phase1_batch(prob)
+    zo, So, sto, _, _ = oracle_batch(orc, prob, S0, x0)
+    ctx = pkg.Context(pkg.default_context().device)
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    db = pkg.DeviceBatch(prob, S0, x0, ctx=ctx)
+    db.solve()
+    ra = db.results()
+    db.use_stats = False
+    db.stats.zero_()
+    db.solve()
+    rl = db.results()
+    assert not rl["stats"]["iters"].any()                      # (the lean launch wrote no statistics)
+    assert np.array_equal(rl["z"], ra["z"]) and np.array_equal(rl["S"], ra["S"]) and np.array_equal(rl["status"], ra["status"])
+    assert_parity(rl["z"], rl["S"], rl["status"], zo, So, sto)

@@ -45,11 +45,11 @@ for p in ("pmc_sq1_default", "pmc_sq2_default", "pmc_sq3_default"):
 if sq and "default_formulation" in res:
     res["default_formulation"]["sq"] = sq
 # the eight-per-CU build (what the launch lanes of the timed region run), from the lanes passes
-f8 = per_launch("pmc_fetch_lanes", "ssqp_wave_kernel<2, true, 2>").get("FETCH_SIZE")
-w8 = per_launch("pmc_write_lanes", "ssqp_wave_kernel<2, true, 2>").get("WRITE_SIZE")
+f8 = per_launch("pmc_fetch_lanes", "ssqp_wave_kernel<2, true, 2,").get("FETCH_SIZE")
+w8 = per_launch("pmc_write_lanes", "ssqp_wave_kernel<2, true, 2,").get("WRITE_SIZE")
 if f8 is not None and w8 is not None:
     res["eight_per_cu_build"] = {"FETCH_SIZE_KiB": f8, "WRITE_SIZE_KiB": w8, "hbm_bytes_per_launch": (2.0 * f8 + w8) * 1024.0,
-                                 "sq": per_launch("pmc_sq1_lanes", "ssqp_wave_kernel<2, true, 2>")}
+                                 "sq": per_launch("pmc_sq1_lanes", "ssqp_wave_kernel<2, true, 2,")}
 # cfg3 (big-factor build): written beside, keyed the same way (bench.py --config cfg3 --pmc-json <that file>)
 f3 = per_launch("pmc_fetch_cfg3").get("FETCH_SIZE")
 w3 = per_launch("pmc_write_cfg3").get("WRITE_SIZE")
