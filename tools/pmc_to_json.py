@@ -22,6 +22,9 @@ def per_launch(passdir, only=None):
             if "ssqp_solve_kernel" in kn or "ssqp_wave_kernel" in kn:
                 # one class per kernel of the hand-over chain (each is launched once per batch, possibly on an empty list)
                 cls = kn.split("(ssqp::SolveParams")[0].split("ssqp_")[-1]
+                # (the lean and the accounting build of a wave kernel are ONE class: bench.py runs one accounting launch and
+                #  times the lean ones -- the counters of a launch are their mean, not their sum)
+                cls = cls.replace(", true>", ">").replace(", false>", ">")
                 acc[r["Counter_Name"]][cls].append(float(r["Counter_Value"]))
     out = {}
     for c, d in acc.items():
