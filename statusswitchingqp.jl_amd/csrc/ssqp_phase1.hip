@@ -121,6 +121,9 @@ __device__ __forceinline__ void wave_order() {
 __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double *vec, int *piv, int n, int *flag) {
     double *urow = vec, *lcol = vec + n;
     const int lane = tid & 63;
+#ifdef SSQP_PHASE_PROFILE
+    const unsigned long long luT0 = __builtin_amdgcn_s_memtime();
+#endif
     for (int k = 0; k < n; ++k) {
         if (tid < 64) {  // the FIRST largest |a(i, k)|, i = k .. n - 1 (the host's strict ">" scan)
             double best = -1.0;
@@ -193,6 +196,10 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
     // columns per wavefront: between two steps the three only need the wavefront's own LDS ordering, no barrier.  P e_c: the
     // host applies the row swaps to e_c in order; the permuted unit vector has its 1 where that sequence of swaps sends c
     const int xs = n + 1;
+#ifdef SSQP_PHASE_PROFILE
+    const unsigned long long luT1 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) (void)__hip_atomic_fetch_add(&g_p1phase[10], luT1 - luT0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     {
         const int wv = tid >> 6;
         const int c = wv * 21 + lane / 3, q = lane % 3;
@@ -241,6 +248,9 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
         }
     }
     __syncthreads();
+#ifdef SSQP_PHASE_PROFILE
+    if (tid == 0) (void)__hip_atomic_fetch_add(&g_p1phase[11], __builtin_amdgcn_s_memtime() - luT1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     for (int e = tid; e < n * n; e += NT1) {
         const int cc = e / n, i = e - cc * n;
         a[e] = x[(size_t)cc * xs + i];
@@ -611,6 +621,35 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
             int *art = piv;   // (the LU's integer scratch is idle here)
             const int nArt = compact_columns(tid, M0, art, &misc[0], [&](int r) { return basis[r] >= N0; });
             constexpr int RG = BIG ? 8 : 6, CG = 4;
+            // inv(B) of a simplex basis is SPARSE while unit columns (slacks, artificials) make up most of B -- cfg5: 3 % to
+            // 30 % of its entries are nonzero over the first 150 of 273 basis changes -- and a term inv(B)[r, t] * a with an
+            // exact zero factor adds +-0.0 to a sum that is never -0.0: leaving it out changes no bit (finite LP data).  Per
+            // group of RG rows the steps t with a nonzero entry in ANY of them are listed once per refresh (one wavefront per
+            // group, ballot order = ascending t); the column loop below walks the list instead of 0 .. M0 - 1.
+            int *tl = reinterpret_cast<int *>(Bm);   // (the LU's scratch, idle here: group g at g (M0 + 1): count, then the steps)
+            {
+                const int wv = tid >> 6, lane = tid & 63;
+                for (int g = wv; g * RG < nArt; g += NT1 / 64) {
+                    int *tg = tl + g * (M0 + 1);
+                    int base = 0;
+                    for (int tb = 0; tb < M0; tb += 64) {
+                        const int t = tb + lane;
+                        bool f = false;
+                        if (t < M0) {
+                            double e[RG];
+#pragma unroll
+                            for (int v = 0; v < RG; ++v) e[v] = invB[(size_t)t * M0 + art[g * RG + v < nArt ? g * RG + v : g * RG]];
+#pragma unroll
+                            for (int v = 0; v < RG; ++v) f = f || (e[v] != 0.0);
+                        }
+                        const unsigned long long m = __ballot(f);
+                        if (f) tg[1 + base + __popcll(m & ((1ull << lane) - 1ull))] = t;
+                        base += __popcll(m);
+                    }
+                    if (lane == 0) tg[0] = base;
+                }
+            }
+            __syncthreads();
             for (int kb = 0; kb < N1; kb += CG * NT1) {
                 int kc[CG];
                 bool on[CG];
@@ -627,6 +666,8 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                 for (int u = 0; u < CG; ++u) sd[u] = 0.0;
                 if (anyOn) {
                     for (int g0 = 0; g0 < nArt; g0 += RG) {
+                        const int *tg = tl + (g0 / RG) * (M0 + 1);
+                        const int nT = tg[0];
                         int rr[RG];
                         double wt[RG];
 #pragma unroll
@@ -639,33 +680,39 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                         for (int v = 0; v < RG; ++v)
 #pragma unroll
                             for (int u = 0; u < CG; ++u) sacc[v][u] = 0.0;
-                        // (the LP's entries of step t + 1 are requested before step t's products are formed: with one
-                        //  workgroup on the chip nobody else hides the L2 round trip)
-                        double at[CG], a1[CG], an[CG], iv[RG], ivn[RG];
-#pragma unroll
-                        for (int u = 0; u < CG; ++u) {
-                            at[u] = A1[kc[u]];
-                            a1[u] = A1[(size_t)(M0 > 1 ? 1 : 0) * N1 + kc[u]];
-                        }
-#pragma unroll
-                        for (int v = 0; v < RG; ++v) iv[v] = invB[rr[v]];
-                        for (int t = 0; t < M0; ++t) {  // (the LP's entries two steps ahead, the row of inv(B) one step ahead)
-                            const int t2 = t + 2 < M0 ? t + 2 : M0 - 1, t1 = t + 1 < M0 ? t + 1 : t;
-#pragma unroll
-                            for (int u = 0; u < CG; ++u) an[u] = A1[(size_t)t2 * N1 + kc[u]];
-#pragma unroll
-                            for (int v = 0; v < RG; ++v) ivn[v] = invB[(size_t)t1 * M0 + rr[v]];
-#pragma unroll
-                            for (int v = 0; v < RG; ++v)
-#pragma unroll
-                                for (int u = 0; u < CG; ++u) sacc[v][u] += iv[v] * at[u];
+                        if (nT > 0) {
+                            // (the LP's entries of step i + 2 are requested before step i's products are formed, the step
+                            //  numbers another step ahead: with one workgroup on the chip nobody else hides the L2 round trip)
+                            double at[CG], a1[CG], an[CG], iv[RG], ivn[RG];
+                            const int s0 = tg[1], s1 = tg[1 + (1 < nT ? 1 : nT - 1)];
+                            int s2 = tg[1 + (2 < nT ? 2 : nT - 1)], sNext = s1;
 #pragma unroll
                             for (int u = 0; u < CG; ++u) {
-                                at[u] = a1[u];
-                                a1[u] = an[u];
+                                at[u] = A1[(size_t)s0 * N1 + kc[u]];
+                                a1[u] = A1[(size_t)s1 * N1 + kc[u]];
                             }
 #pragma unroll
-                            for (int v = 0; v < RG; ++v) iv[v] = ivn[v];
+                            for (int v = 0; v < RG; ++v) iv[v] = invB[(size_t)s0 * M0 + rr[v]];
+                            for (int i = 0; i < nT; ++i) {
+                                const int s3 = tg[1 + (i + 3 < nT ? i + 3 : nT - 1)];
+#pragma unroll
+                                for (int u = 0; u < CG; ++u) an[u] = A1[(size_t)s2 * N1 + kc[u]];
+#pragma unroll
+                                for (int v = 0; v < RG; ++v) ivn[v] = invB[(size_t)sNext * M0 + rr[v]];
+#pragma unroll
+                                for (int v = 0; v < RG; ++v)
+#pragma unroll
+                                    for (int u = 0; u < CG; ++u) sacc[v][u] += iv[v] * at[u];
+#pragma unroll
+                                for (int u = 0; u < CG; ++u) {
+                                    at[u] = a1[u];
+                                    a1[u] = an[u];
+                                }
+#pragma unroll
+                                for (int v = 0; v < RG; ++v) iv[v] = ivn[v];
+                                sNext = s2;
+                                s2 = s3;
+                            }
                         }
 #pragma unroll
                         for (int v = 0; v < RG; ++v)

@@ -27,6 +27,9 @@ print("config", name, "nprob", nprob, "simplex passes per QP %.1f, basis changes
     it / nprob, bc / nprob, tot / nprob))
 for i, n in enumerate(names):
     print("%-34s %6.2f %%  %9.0f cycles per QP" % (n, 100.0 * out[i] / tot, out[i] / nprob))
+if out[10] or out[11]:
+    print("  inv(lu(B)) of the many-rows build: elimination %.0f, columns of the inverse %.0f cycles per basis change" % (
+        out[10] / max(bc, 1), out[11] / max(bc, 1)))
 
 # ---- the one-wavefront-per-QP kernel (the default where it applies): its own stamps
 lib.ssqp_debug_phase1_wave_phases.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
