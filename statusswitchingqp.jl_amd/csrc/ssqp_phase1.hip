@@ -107,90 +107,122 @@ __device__ __forceinline__ void wave_order() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
-// inv(lu(a)) in place for the n x n column-major LDS matrix a, partial pivoting, the host's operation order per element
-// (ssqp_host.cpp invert_lu).  Scratch: x (n x (n + 1) doubles), vec (2 n doubles), piv (2 n ints).  Returns false when a
-// pivot is exactly 0.  Three barriers per elimination step:
-//   * the pivot search of column k is a wavefront reduction (first maximum: value, then smallest row among the ties) --
-//     one thread scanning the column was 4 k cycles of dependent LDS reads per step;
-//   * the pivot row (the U row) and the scaled column (the L column) are staged in `vec`, so that the trailing update reads
-//     nothing another thread writes in the same phase: element (i, j) is read at the row the swap would have brought to i
-//     and written at i -- the swap itself is never a separate pass;
-//   * the columns of the inverse take ONE THREAD each (18 per wavefront), forward and backward substitution in private,
-//     no barrier: the factors are read from one address by every thread (broadcast), the column lives in `x` with a
-//     stride of n + 1 doubles (conflict-free for the eighteen lanes of a wavefront).
+// inv(lu(a)) in place for the n x n column-major LDS matrix a (n <= 128), partial pivoting, the host's operation order per
+// element (ssqp_host.cpp invert_lu).  Scratch: x (n x (n + 1) doubles), vec (2 n doubles), piv (2 n ints).  Returns false
+// when a pivot is exactly 0.
+//
+// A simplex basis is mostly UNIT columns (slacks, artificials): cfg5's 72 x 72 bases hold 1 to 11 dense columns, their
+// inverses 3 % to 30 % nonzeros.  The host's loops run over every element; here every step first lists what is NOT an exact
+// zero, and an update a -= l * u with l or u exactly 0 is left out.  That changes no bit of the inverse's nonzero entries
+// and no decision taken on it: the only thing an update by +-0.0 can do is turn a -0.0 into +0.0, the trailing matrix is
+// only ever subtracted from (a difference is never -0.0 unless its first operand was), and a zero of either sign gives the
+// same pivot search (|.|), the same products (+-0.0, added to sums that are never -0.0) and the same "pivot is exactly 0"
+// verdict.  Likewise a column entry of the inverse that is 0 before its division stays +0.0 where the host has 0 / U = +-0.0.
+//   * elimination step k: wavefront 0 finds the pivot (first maximum: value, then smallest row among the ties), lists the
+//     nonzero rows of the L column and the nonzero columns of the U row by ballot, and publishes 1 / pivot; after ONE barrier
+//     the rows k and p change places in every column and column k is scaled (distinct threads, distinct elements); the
+//     trailing update -- a second barrier, and a third behind it -- runs over (listed rows) x (listed columns) and not at
+//     all when the L column is zero, the common case;
+//   * columns of the inverse: three lanes of one wavefront per column, 21 columns per wavefront, no barrier between steps; a
+//     forward step whose L column is zero is not walked at all (a bit mask in scalar registers), neither is a step at which
+//     none of the wavefront's columns has a nonzero entry, and a backward step whose U column is empty is the division only.
 __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double *vec, int *piv, int n, int *flag) {
-    double *urow = vec, *lcol = vec + n;
     const int lane = tid & 63;
+    int *Lnz = reinterpret_cast<int *>(vec), *Unz = Lnz + n, *hasU = Lnz + 2 * n;   // (vec: 2 n doubles = 4 n ints)
+    int *stepInfo = piv + n;                                                         // nL | nU << 8 of step k
+    double *rinv = x;                                                                // 1 / pivot of step k (x is idle until the columns start)
 #ifdef SSQP_PHASE_PROFILE
     const unsigned long long luT0 = __builtin_amdgcn_s_memtime();
 #endif
+    if (tid < 64) {
+        for (int j = lane; j < n; j += 64) hasU[j] = 0;
+        wave_order();
+    }
     for (int k = 0; k < n; ++k) {
         if (tid < 64) {  // the FIRST largest |a(i, k)|, i = k .. n - 1 (the host's strict ">" scan)
+            const double *colk = a + (size_t)k * n;
             double best = -1.0;
             int bi = 0x7fffffff;
             for (int i = k + lane; i < n; i += 64) {
-                const double v = fabs(a[(size_t)k * n + i]);
+                const double v = fabs(colk[i]);
                 if (v > best) best = v, bi = i;   // (ascending i inside the lane)
             }
             const KeyMin km = wave_keymin(KeyMin{-best, bi});
+            const int p = km.ord < n ? km.ord : k;   // (km.ord = 0x7fffffff: nothing but NaN in the column)
+            int nL = 0, nU = 0;
+            for (int ib = k + 1; ib < n; ib += 64) {  // rows of the L column that are not exactly zero (positions after the swap)
+                const int i = ib + lane;
+                const bool f = i < n && colk[i == p ? k : i] != 0.0;
+                const unsigned long long m = __ballot(f);
+                if (f) Lnz[nL + __popcll(m & ((1ull << lane) - 1ull))] = i;
+                nL += __popcll(m);
+            }
+            for (int jb = k + 1; jb < n; jb += 64) {  // columns of the U row (row p before the swap) that are not exactly zero
+                const int j = jb + lane;
+                const bool f = j < n && a[(size_t)j * n + p] != 0.0;
+                const unsigned long long m = __ballot(f);
+                if (f) {
+                    Unz[nU + __popcll(m & ((1ull << lane) - 1ull))] = j;
+                    hasU[j] = 1;
+                }
+                nU += __popcll(m);
+            }
             if (lane == 0) {
-                piv[k] = km.ord;
-                *flag = (km.v == 0.0) ? 0 : 1;   // (-best == -0.0: the whole column is zero)
+                piv[k] = p;
+                stepInfo[k] = nL | (nU << 8);
+                rinv[k] = 1.0 / colk[p];
+                *flag = (km.v == 0.0 || km.ord >= n) ? 0 : 1;   // (-best == -0.0: the whole column is zero)
             }
         }
         __syncthreads();
         if (!*flag) return false;
-        const int p = piv[k];
-        // stage the pivot row (columns k .. n - 1 of old row p) and the scaled column (rows k + 1 .. n - 1, post-swap order);
-        // columns j < k: the L part of rows k and p changes places
-        {
-            const double r = 1.0 / a[(size_t)k * n + p];   // (every thread: cheaper than a broadcast through LDS and a barrier)
-            for (int j = tid; j < n; j += NT1) {
-                if (j >= k) urow[j] = a[(size_t)j * n + p];
-                else if (p != k) {
-                    const double t = a[(size_t)j * n + k];
-                    a[(size_t)j * n + k] = a[(size_t)j * n + p];
-                    a[(size_t)j * n + p] = t;
-                }
+        const int p = piv[k], info = stepInfo[k];
+        // rows k and p change places in every column but k (thread j < 128 takes column j); column k: a(i, k) = a(i', k) / pivot
+        // for i > k with i' the row the swap brings to i, and the pivot itself moves to (k, k) (thread 128 + i - k - 1)
+        if (tid < 128) {
+            if (tid < n && tid != k && p != k) {
+                double *colj = a + (size_t)tid * n;
+                const double t = colj[k];
+                colj[k] = colj[p];
+                colj[p] = t;
             }
-            for (int i = k + 1 + tid; i < n; i += NT1) {
-                const int src = (i == p) ? k : i;                   // (the row the swap brings to i)
-                lcol[i] = a[(size_t)k * n + src] * r;               // a(i, k) *= r
+        } else {
+            const int i = k + 1 + (tid - 128);
+            if (i < n) {
+                double *colk = a + (size_t)k * n;
+                const double r = rinv[k];
+                const double src = colk[i == p ? k : i], pv = colk[p];
+                colk[i] = src * r;               // a(i, k) *= 1 / a(k, k)
+                if (i == p) colk[k] = pv;
             }
         }
         __syncthreads();
-        // trailing update a(i, j) -= a(i, k) * a(k, j) for i, j > k, reading (i, j) where the swap would have put it; the
-        // thread that handles row p of a column also writes row k of it (the pivot row), and column k takes the L column.
-        // Thread (cj = tid >> 4, ri = tid & 15) takes the rows k + 1 + ri + 16 m of the columns k + 1 + cj + 16 g: no
-        // integer division per element, sixteen neighbours read 128 contiguous bytes, and a column's rows (five at most for
-        // n <= 80, in rounds of five beyond) go out in one LDS round trip
-        {
+        const int nL = info & 255, nU = info >> 8;
+        if (nL > 0 && nU > 0) {
+            // a(i, j) -= a(i, k) * a(k, j) over the listed rows and columns: thread (cj = tid >> 4, ri = tid & 15) takes the
+            // listed rows ri + 16 m of the listed columns cj + 16 g, five rows per LDS round trip
             const int cj = tid >> 4, ri = tid & 15;
-            for (int j = k + 1 + cj; j < n; j += NT1 / 16) {
-                const double uj = urow[j];
-                double *colj = a + (size_t)j * n;
-                for (int i0 = k + 1 + ri; i0 < n; i0 += 16 * 5) {
+            const double *colk = a + (size_t)k * n;
+            for (int jj = cj; jj < nU; jj += NT1 / 16) {
+                double *colj = a + (size_t)Unz[jj] * n;
+                const double uj = colj[k];
+                for (int i0 = ri; i0 < nL; i0 += 16 * 5) {
+                    int ix[5];
                     double ov[5], lv[5];
 #pragma unroll
-                    for (int m = 0; m < 5; ++m) {
-                        const int i = i0 + 16 * m < n ? i0 + 16 * m : i0;
-                        ov[m] = colj[(i == p) ? k : i];
-                        lv[m] = lcol[i];
-                    }
+                    for (int m = 0; m < 5; ++m) ix[m] = Lnz[i0 + 16 * m < nL ? i0 + 16 * m : i0];
 #pragma unroll
                     for (int m = 0; m < 5; ++m) {
-                        const int i = i0 + 16 * m;
-                        if (i < n) {
-                            colj[i] = ov[m] - lv[m] * uj;
-                            if (i == p) colj[k] = uj;
-                        }
+                        ov[m] = colj[ix[m]];
+                        lv[m] = colk[ix[m]];
                     }
+#pragma unroll
+                    for (int m = 0; m < 5; ++m)
+                        if (i0 + 16 * m < nL) colj[ix[m]] = ov[m] - lv[m] * uj;
                 }
             }
-            for (int i = k + 1 + tid; i < n; i += NT1) a[(size_t)k * n + i] = lcol[i];
-            if (tid == 0) a[(size_t)k * n + k] = urow[k];
+            __syncthreads();
         }
-        __syncthreads();
     }
     // columns of the inverse: L U x_c = P e_c, THREE lanes of one wavefront per column (lane q takes the rows i = q mod 3), 21
     // columns per wavefront: between two steps the three only need the wavefront's own LDS ordering, no barrier.  P e_c: the
@@ -204,6 +236,14 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
         const int wv = tid >> 6;
         const int c = wv * 21 + lane / 3, q = lane % 3;
         const bool mine = lane < 63 && c < n;
+        // the steps with a nonzero L column / a nonempty U column, as bit masks (steps 0 .. 63, 64 .. 127)
+        unsigned long long fwd[2], upd[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kk = 64 * h + lane;
+            fwd[h] = __ballot(kk < n && (stepInfo[kk < n ? kk : 0] & 255) != 0);
+            upd[h] = __ballot(kk < n && hasU[kk < n ? kk : 0] != 0);
+        }
         double *xc = x + (size_t)(mine ? c : 0) * xs;
         if (mine) {
             int pos = c;
@@ -231,18 +271,27 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
                     if (i0 + 3 * m < hi) xc[i0 + 3 * m] = xv[m] - fv[m] * t;
             }
         };
-        // (every wavefront walks all n steps -- the step count is uniform -- whether or not a lane has a column)
-        for (int k = 0; k < n; ++k) {  // forward: x[i] -= L(i, k) x[k]  for i > k  (the host's "t != 0" guard only skips zeros)
-            const double t = xc[k];
-            if (mine) axpy(a + (size_t)k * n, k + 1, n, t);
-            wave_order();
+        // forward: x[i] -= L(i, k) x[k]  for i > k  (the host's "t != 0" guard only skips zeros; so does the mask)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            unsigned long long m = fwd[h];
+            while (m) {
+                const int k = 64 * h + __builtin_ctzll(m);
+                m &= m - 1ull;
+                const double t = xc[k];
+                if (__ballot(mine && t != 0.0) == 0ull) continue;   // (none of this wavefront's columns has an entry here)
+                if (mine) axpy(a + (size_t)k * n, k + 1, n, t);
+                wave_order();
+            }
         }
         for (int k = n - 1; k >= 0; --k) {  // backward: x[k] /= U(k, k), then x[i] -= U(i, k) x[k]  for i < k
-            const double t = xc[k] / a[(size_t)k * n + k];
+            const double xk = xc[k];
+            if (__ballot(mine && xk != 0.0) == 0ull) continue;
+            const double t = xk / a[(size_t)k * n + k];
             wave_order();   // (the three lanes have read x[k])
             if (mine) {
                 if (k % 3 == q) xc[k] = t;
-                axpy(a + (size_t)k * n, 0, k, t);
+                if ((upd[k >> 6] >> (k & 63)) & 1ull) axpy(a + (size_t)k * n, 0, k, t);
             }
             wave_order();
         }
@@ -536,6 +585,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
     // (the column of A1 / of Y a thread works on is pulled into registers first when M0 <= 16: the sums below are
     //  sequential by construction, and with a dependent global load per term each term would cost a cache round trip)
     constexpr int MC = 12;
+    constexpr bool FEW = !BIG;   // (launch_phase1 picks the build by M0 <= 12 = MC = LUC: the other build's paths are not compiled in)
     // The host keeps Y = invB * A[:, nonbasic] (Simplex.jl:595) and reads it in two places: the pricing (Y[:,k] . c[basis])
     // and the xb sum (Y[:,k] x_k of the nonbasic columns at a nonzero bound).  Here Y[:,k] only ever exists in the
     // registers of the thread that owns column k: the pricing's dot product is formed at once (same order r = 0 .. M0 - 1
@@ -552,7 +602,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
             const int row = e < J ? M + e : e - J;
             const double val = e < J ? 1.0 : sgnArt[row];
             double sd = 0.0;
-            if (M0 <= MC) {
+            if (FEW) {
                 double iv[MC], cb[MC];
 #pragma unroll
                 for (int r = 0; r < MC; ++r) {
@@ -575,7 +625,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
             sdot[k] = sd;
         }
         auto general = [&](int k) { return k < N1 && !(k >= N && (k < N + J || k >= N0)); };  // (unit columns: done above)
-        if (M0 <= MC) {
+        if (FEW) {
             // two columns per thread and round (k, k + NT1): the entries of invB a row's sums need are read ONCE for both --
             // LDS reads, not arithmetic, are what sixteen wavefronts per CU queue for here -- and TOGETHER, from clamped
             // addresses (a read under the "t < M0" guard waits for its own round trip, eleven in a row)
@@ -768,7 +818,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
         const double *ak = A1 + k;  // (entry t of column k: ak[t * N1])
         for (int r = tid; r < M0; r += NT1) {
             double s = 0.0;
-            if (M0 <= MC) {  // (the column's entries and the row of invB are requested together: one round trip)
+            if (FEW) {  // (the column's entries and the row of invB are requested together: one round trip)
                 double av[MC], iv[MC];
 #pragma unroll
                 for (int t = 0; t < MC; ++t) {
@@ -830,7 +880,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                 if (better) lr = ratio, li = m, lrow = j, lto = (code == 1) ? SSQP_DN : SSQP_UP;
                 ++m;
             };
-            if (M0 <= MC) {
+            if (FEW) {
                 double rt[MC];
                 int cd[MC];
 #pragma unroll
@@ -887,7 +937,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                 nonbasic[k] = 0;
                 nonbasic[leaving] = 1;
                 basis[action - 1] = k;
-                if (M0 <= MC) {  // sort(basis) in registers (the basis was sorted before the exchange: one pass each way)
+                if (FEW) {  // sort(basis) in registers (the basis was sorted before the exchange: one pass each way)
                     int bs[MC];
 #pragma unroll
                     for (int a2 = 0; a2 < MC; ++a2) bs[a2] = (a2 < M0) ? basis[a2 < M0 ? a2 : 0] : 0x7fffffff;
@@ -923,7 +973,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
             P1_STAMP(5);  // basis sort + gather
             P1_COUNT(15);
             bool okLu;
-            if (M0 <= LUC) {  // (one wavefront, the matrix in registers; the others wait for its verdict)
+            if (FEW) {  // (one wavefront, the matrix in registers; the others wait for its verdict)
                 if (tid < 64) {
                     const bool okw = invert_lu_cols(invB, Bm, piv, M0);
                     if (tid == 0) misc[1] = okw ? 1 : 0;
@@ -955,6 +1005,64 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
             // (the host's order): the PRODUCTS of a chunk of columns are formed by all threads at once (one memory round
             // trip for the chunk instead of one per term), the adds stay in order
             double a2 = 0.0;
+            if (!FEW) {
+                // Many rows: the listed columns of the LP are STAGED in LDS a chunk at a time (the LU's scratch, idle here) --
+                // a (column, row) element per thread walking its 72 terms through L2 was nine dependent round trips, 200 k
+                // cycles per pass on cfg5 -- and thread (g, r) forms row r of the columns g, g + G, ... of the chunk: one entry
+                // of inv(B) is read per step for up to XBC columns, the LP's entries are broadcast reads.  Per element the
+                // sum runs over t ascending, as refreshY forms Y[r, k].
+                constexpr int XBC = 16;
+                const int G = NT1 / M0 < 4 ? (NT1 / M0 < 2 ? 2 : NT1 / M0) : 4;   // column groups (M0 <= 128)
+                const int chunk = XB_CHUNK < M0 ? XB_CHUNK : M0;                   // (chunk x M0 doubles fit the scratch)
+                const int g = tid / M0, r = tid - g * M0;
+                double *Ac = Bm;                                                   // column t of the chunk at t * M0
+                for (int t0 = 0; t0 < cnt; t0 += chunk) {
+                    const int nt = cnt - t0 < chunk ? cnt - t0 : chunk;
+                    for (int e = tid; e < nt * M0; e += NT1) {
+                        const int t = e / M0, t2 = e - t * M0;
+                        Ac[e] = A1[(size_t)t2 * N1 + list[t0 + t]];
+                    }
+                    __syncthreads();
+                    if (g < G) {
+                        double y[XBC];
+#pragma unroll
+                        for (int c = 0; c < XBC; ++c) y[c] = 0.0;
+                        const int nc = (nt - g + G - 1) / G;                       // this thread's columns: g + c G < nt
+                        for (int t2 = 0; t2 < M0; t2 += 2) {                       // (two steps' reads go out together)
+                            const int t2b = t2 + 1 < M0 ? t2 + 1 : t2;
+                            const double iv0 = invB[(size_t)t2 * M0 + r], iv1 = invB[(size_t)t2b * M0 + r];
+                            double a0[XBC], a1[XBC];
+#pragma unroll
+                            for (int c = 0; c < XBC; ++c) {
+                                const int t = c < nc ? g + c * G : g < nt ? g : 0;
+                                a0[c] = Ac[(size_t)t * M0 + t2];
+                                a1[c] = Ac[(size_t)t * M0 + t2b];
+                            }
+#pragma unroll
+                            for (int c = 0; c < XBC; ++c) y[c] += iv0 * a0[c];
+                            if (t2 + 1 < M0) {
+#pragma unroll
+                                for (int c = 0; c < XBC; ++c) y[c] += iv1 * a1[c];
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < XBC; ++c)
+                            if (c < nc) terms[(size_t)(g + c * G) * M0 + r] = y[c] * x[list[t0 + g + c * G]];
+                    }
+                    __syncthreads();
+                    if (tid < M0) {  // (eight terms per LDS round trip, added in order)
+                        for (int t0b = 0; t0b < nt; t0b += 8) {
+                            double tv[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) tv[q] = terms[(size_t)(t0b + q < nt ? t0b + q : t0b) * M0 + tid];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q)
+                                if (t0b + q < nt) a2 += tv[q];
+                        }
+                    }
+                    __syncthreads();
+                }
+            } else
             for (int t0 = 0; t0 < cnt; t0 += XB_CHUNK) {
                 const int nt = cnt - t0 < XB_CHUNK ? cnt - t0 : XB_CHUNK;
                 // (M0 <= 16: thread -> (column t = tid / 16 + 16 i, row r = tid % 16), no integer division per element)
@@ -971,7 +1079,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                     }
                     const int kk = list[t0 + t];
                     double y = 0.0;  // Y[r, kk] = (invB * A1[:, kk])_r, as refreshY forms it
-                    if (M0 <= MC) {
+                    if (FEW) {
                         double av[MC], iv[MC];
 #pragma unroll
                         for (int t2 = 0; t2 < MC; ++t2) {
@@ -1013,7 +1121,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
             }
             for (int r = tid; r < M0; r += NT1) {
                 double s = 0.0;
-                if (M0 <= MC) {
+                if (FEW) {
                     double iv[MC], rv[MC];
 #pragma unroll
                     for (int t = 0; t < MC; ++t) {
