@@ -138,44 +138,79 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
         for (int j = lane; j < n; j += 64) hasU[j] = 0;
         wave_order();
     }
-    for (int k = 0; k < n; ++k) {
-        if (tid < 64) {  // the FIRST largest |a(i, k)|, i = k .. n - 1 (the host's strict ">" scan)
-            const double *colk = a + (size_t)k * n;
-            double best = -1.0;
-            int bi = 0x7fffffff;
-            for (int i = k + lane; i < n; i += 64) {
-                const double v = fabs(colk[i]);
-                if (v > best) best = v, bi = i;   // (ascending i inside the lane)
-            }
-            const KeyMin km = wave_keymin(KeyMin{-best, bi});
-            const int p = km.ord < n ? km.ord : k;   // (km.ord = 0x7fffffff: nothing but NaN in the column)
-            int nL = 0, nU = 0;
-            for (int ib = k + 1; ib < n; ib += 64) {  // rows of the L column that are not exactly zero (positions after the swap)
-                const int i = ib + lane;
-                const bool f = i < n && colk[i == p ? k : i] != 0.0;
-                const unsigned long long m = __ballot(f);
-                if (f) Lnz[nL + __popcll(m & ((1ull << lane) - 1ull))] = i;
-                nL += __popcll(m);
-            }
-            for (int jb = k + 1; jb < n; jb += 64) {  // columns of the U row (row p before the swap) that are not exactly zero
-                const int j = jb + lane;
-                const bool f = j < n && a[(size_t)j * n + p] != 0.0;
-                const unsigned long long m = __ballot(f);
-                if (f) {
-                    Unz[nU + __popcll(m & ((1ull << lane) - 1ull))] = j;
-                    hasU[j] = 1;
+    int *ctrl = Lnz + 3 * n;   // [0]: the step the workgroup takes up after the barrier (n: none is left)
+    for (int k = 0;;) {
+        if (tid < 64) {
+            // wavefront 0 walks the steps from k on.  A step whose L column is zero updates nothing: its whole effect is the
+            // exchange of two rows, which this wavefront does itself (two elements per column) before it looks at the next
+            // column -- no barrier until a step with a nonzero L column turns up, and most steps have none
+            int kk = k;
+            bool ok;
+            for (;;) {
+                const double *colk = a + (size_t)kk * n;
+                double best = -1.0;   // the FIRST largest |a(i, kk)|, i = kk .. n - 1 (the host's strict ">" scan)
+                int bi = 0x7fffffff;
+                for (int i = kk + lane; i < n; i += 64) {
+                    const double v = fabs(colk[i]);
+                    if (v > best) best = v, bi = i;   // (ascending i inside the lane)
                 }
-                nU += __popcll(m);
+                const KeyMin km = wave_keymin(KeyMin{-best, bi});
+                ok = !(km.v == 0.0 || km.ord >= n);   // (-best == -0.0: the whole column is zero; no order: nothing but NaN)
+                if (!ok) break;
+                const int p = km.ord;
+                int nL = 0, nU = 0;
+                for (int ib = kk + 1; ib < n; ib += 64) {  // rows of the L column that are not exactly zero (positions after the swap)
+                    const int i = ib + lane;
+                    const bool f = i < n && colk[i == p ? kk : i] != 0.0;
+                    const unsigned long long m = __ballot(f);
+                    if (f) Lnz[nL + __popcll(m & ((1ull << lane) - 1ull))] = i;
+                    nL += __popcll(m);
+                }
+                if (nL == 0) {
+                    for (int jb = 0; jb < n; jb += 64) {
+                        const int j = jb + lane;
+                        double *colj = a + (size_t)(j < n ? j : 0) * n;
+                        const double vk = colj[kk], vp = colj[p];
+                        if (j < n && j > kk && vp != 0.0) hasU[j] = 1;   // (row p before the swap = the U row)
+                        if (j < n && p != kk) {
+                            colj[kk] = vp;
+                            colj[p] = vk;
+                        }
+                    }
+                    if (lane == 0) {
+                        piv[kk] = p;
+                        stepInfo[kk] = 0;
+                    }
+                    wave_order();
+                    if (++kk == n) break;
+                    continue;
+                }
+                for (int jb = kk + 1; jb < n; jb += 64) {  // columns of the U row (row p before the swap) that are not exactly zero
+                    const int j = jb + lane;
+                    const bool f = j < n && a[(size_t)j * n + p] != 0.0;
+                    const unsigned long long m = __ballot(f);
+                    if (f) {
+                        Unz[nU + __popcll(m & ((1ull << lane) - 1ull))] = j;
+                        hasU[j] = 1;
+                    }
+                    nU += __popcll(m);
+                }
+                if (lane == 0) {
+                    piv[kk] = p;
+                    stepInfo[kk] = nL | (nU << 8);
+                    rinv[kk] = 1.0 / colk[p];
+                }
+                break;
             }
             if (lane == 0) {
-                piv[k] = p;
-                stepInfo[k] = nL | (nU << 8);
-                rinv[k] = 1.0 / colk[p];
-                *flag = (km.v == 0.0 || km.ord >= n) ? 0 : 1;   // (-best == -0.0: the whole column is zero)
+                *flag = ok ? 1 : 0;
+                ctrl[0] = kk;
             }
         }
         __syncthreads();
         if (!*flag) return false;
+        k = ctrl[0];
+        if (k >= n) break;
         const int p = piv[k], info = stepInfo[k];
         // rows k and p change places in every column but k (thread j < 128 takes column j); column k: a(i, k) = a(i', k) / pivot
         // for i > k with i' the row the swap brings to i, and the pivot itself moves to (k, k) (thread 128 + i - k - 1)
@@ -223,6 +258,7 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
             }
             __syncthreads();
         }
+        if (++k >= n) break;
     }
     // columns of the inverse: L U x_c = P e_c, THREE lanes of one wavefront per column (lane q takes the rows i = q mod 3), 21
     // columns per wavefront: between two steps the three only need the wavefront's own LDS ordering, no barrier.  P e_c: the
@@ -284,16 +320,42 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
                 wave_order();
             }
         }
-        for (int k = n - 1; k >= 0; --k) {  // backward: x[k] /= U(k, k), then x[i] -= U(i, k) x[k]  for i < k
-            const double xk = xc[k];
-            if (__ballot(mine && xk != 0.0) == 0ull) continue;
-            const double t = xk / a[(size_t)k * n + k];
-            wave_order();   // (the three lanes have read x[k])
-            if (mine) {
-                if (k % 3 == q) xc[k] = t;
-                if ((upd[k >> 6] >> (k & 63)) & 1ull) axpy(a + (size_t)k * n, 0, k, t);
+        // backward: x[k] /= U(k, k), then x[i] -= U(i, k) x[k]  for i < k -- over the steps with a nonempty U column, last
+        // first.  An entry whose own U column is empty updates nobody: its division waits until every step that updates IT is
+        // through and is then one of many independent ones (same operands as at the host's step k, so the same bits)
+#pragma unroll
+        for (int h = 1; h >= 0; --h) {
+            unsigned long long m = upd[h];
+            while (m) {
+                const int bit = 63 - __builtin_clzll(m);
+                const int k = 64 * h + bit;
+                m &= ~(1ull << bit);
+                const double xk = xc[k];
+                if (__ballot(mine && xk != 0.0) == 0ull) continue;
+                const double t = xk / a[(size_t)k * n + k];
+                wave_order();   // (the three lanes have read x[k])
+                if (mine) {
+                    if (k % 3 == q) xc[k] = t;
+                    axpy(a + (size_t)k * n, 0, k, t);
+                }
+                wave_order();
             }
-            wave_order();
+        }
+        if (mine) {
+            for (int i0 = q; i0 < n; i0 += 24) {
+                double xv[8], dv[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int i = i0 + 3 * m < n ? i0 + 3 * m : i0;
+                    xv[m] = xc[i];
+                    dv[m] = a[(size_t)i * n + i];
+                }
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int i = i0 + 3 * m;
+                    if (i < n && !((upd[i >> 6] >> (i & 63)) & 1ull) && xv[m] != 0.0) xc[i] = xv[m] / dv[m];
+                }
+            }
         }
     }
     __syncthreads();
@@ -475,7 +537,8 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
     // ---- LDS: invB, Bm (M0 x M0 each), rhs, xb, pvec, start (M0 each), small integers
     double *invB = reinterpret_cast<double *>(smem);
     double *Bm = invB + (size_t)M0 * M0;
-    double *rhs = Bm + (size_t)M0 * (M0 + 1);      // (Bm: M0 x (M0 + 1), the padded columns of the inverse while they are formed)
+    double *rhs = Bm + (size_t)M0 * (M0 + (BIG ? 8 : 1));   // (Bm: M0 x (M0 + 1), the padded columns of the inverse while they are formed;
+                                                             //  many rows: M0 x (M0 + 8), the refresh packs rows of inv(B) there)
     double *xb = rhs + M0;
     double *pv = xb + M0;
     double *acc = pv + M0;
@@ -668,6 +731,9 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
             // columns (the first version walked one column with four rows and a dependent global load per term: 6.2 M cycles
             // per refresh at M0 = 72, 80 % of cfg5's Phase-1).  Per element the sums keep the host's order: t ascending inside
             // a row, rows ascending.
+#ifdef SSQP_PHASE_PROFILE
+            const unsigned long long yT0 = __builtin_amdgcn_s_memtime();
+#endif
             int *art = piv;   // (the LU's integer scratch is idle here)
             const int nArt = compact_columns(tid, M0, art, &misc[0], [&](int r) { return basis[r] >= N0; });
             constexpr int RG = BIG ? 8 : 6, CG = 4;
@@ -676,30 +742,45 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
             // exact zero factor adds +-0.0 to a sum that is never -0.0: leaving it out changes no bit (finite LP data).  Per
             // group of RG rows the steps t with a nonzero entry in ANY of them are listed once per refresh (one wavefront per
             // group, ballot order = ascending t); the column loop below walks the list instead of 0 .. M0 - 1.
-            int *tl = reinterpret_cast<int *>(Bm);   // (the LU's scratch, idle here: group g at g (M0 + 1): count, then the steps)
+            int *tl = reinterpret_cast<int *>(terms);   // (the xb sum's staging, idle here: group g at g (M0 + 1): count, then the steps)
+            double *IV = Bm;                             // (the LU's scratch, idle here: the listed steps' entries of a group's RG rows,
+                                                         //  RG contiguous doubles per step, group g at g M0 RG)
             {
                 const int wv = tid >> 6, lane = tid & 63;
                 for (int g = wv; g * RG < nArt; g += NT1 / 64) {
                     int *tg = tl + g * (M0 + 1);
+                    double *ivg = IV + (size_t)g * M0 * RG;
                     int base = 0;
                     for (int tb = 0; tb < M0; tb += 64) {
                         const int t = tb + lane;
-                        bool f = false;
+                        int rows = 0;   // bit v: row v of the group has a nonzero entry at step t
+                        double e[RG];
+#pragma unroll
+                        for (int v = 0; v < RG; ++v) e[v] = 0.0;
                         if (t < M0) {
-                            double e[RG];
 #pragma unroll
                             for (int v = 0; v < RG; ++v) e[v] = invB[(size_t)t * M0 + art[g * RG + v < nArt ? g * RG + v : g * RG]];
 #pragma unroll
-                            for (int v = 0; v < RG; ++v) f = f || (e[v] != 0.0);
+                            for (int v = 0; v < RG; ++v) rows |= (g * RG + v < nArt && e[v] != 0.0) ? 1 << v : 0;
                         }
+                        const bool f = rows != 0;
                         const unsigned long long m = __ballot(f);
-                        if (f) tg[1 + base + __popcll(m & ((1ull << lane) - 1ull))] = t;
+                        if (f) {
+                            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                            tg[1 + pos] = t | (rows << 8);
+#pragma unroll
+                            for (int v = 0; v < RG; ++v) ivg[(size_t)pos * RG + v] = e[v];
+                        }
                         base += __popcll(m);
                     }
                     if (lane == 0) tg[0] = base;
                 }
             }
             __syncthreads();
+#ifdef SSQP_PHASE_PROFILE
+            const unsigned long long yT1 = __builtin_amdgcn_s_memtime();
+            if (tid == 0) (void)__hip_atomic_fetch_add(&g_p1phase[12], yT1 - yT0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
             for (int kb = 0; kb < N1; kb += CG * NT1) {
                 int kc[CG];
                 bool on[CG];
@@ -733,35 +814,58 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                         if (nT > 0) {
                             // (the LP's entries of step i + 2 are requested before step i's products are formed, the step
                             //  numbers another step ahead: with one workgroup on the chip nobody else hides the L2 round trip)
-                            double at[CG], a1[CG], an[CG], iv[RG], ivn[RG];
-                            const int s0 = tg[1], s1 = tg[1 + (1 < nT ? 1 : nT - 1)];
-                            int s2 = tg[1 + (2 < nT ? 2 : nT - 1)], sNext = s1;
+                            // (list entries: step | rows << 8 -- a step adds to the sums of the rows that have an entry there and
+                            //  to no others: the diagonal of an artificial row is a step of its own, nonzero in that row alone.
+                            //  What bounds this loop is instruction issue -- 64 double-precision operations per full step, and
+                            //  as many again for addresses, copies and waits in its first version -- so: the rows' entries come
+                            //  packed (RG contiguous doubles per listed step, one address), the LP's entries through a scalar
+                            //  row base plus the thread's column offset, in BLOCKS of four steps requested one block ahead, and
+                            //  the two register sets change roles instead of being copied)
+                            constexpr int SB = 4;
+                            const double *ivp = IV + (size_t)(g0 / RG) * M0 * RG;
+                            int ea[SB], eb[SB];
+                            double bufA[SB][CG], bufB[SB][CG], iv[RG];
 #pragma unroll
-                            for (int u = 0; u < CG; ++u) {
-                                at[u] = A1[(size_t)s0 * N1 + kc[u]];
-                                a1[u] = A1[(size_t)s1 * N1 + kc[u]];
+                            for (int q = 0; q < SB; ++q) ea[q] = uni(tg[1 + (q < nT ? q : nT - 1)]);
+#pragma unroll
+                            for (int q = 0; q < SB; ++q) {
+                                const double *rowp = A1 + (size_t)(ea[q] & 255) * N1;
+#pragma unroll
+                                for (int u = 0; u < CG; ++u) bufA[q][u] = rowp[kc[u]];
                             }
 #pragma unroll
-                            for (int v = 0; v < RG; ++v) iv[v] = invB[(size_t)s0 * M0 + rr[v]];
-                            for (int i = 0; i < nT; ++i) {
-                                const int s3 = tg[1 + (i + 3 < nT ? i + 3 : nT - 1)];
+                            for (int v = 0; v < RG; ++v) iv[v] = ivp[v];
+                            auto block = [&](double (&cu)[SB][CG], double (&nx)[SB][CG], int (&ecu)[SB], int (&enx)[SB], int ib) {
 #pragma unroll
-                                for (int u = 0; u < CG; ++u) an[u] = A1[(size_t)s2 * N1 + kc[u]];
+                                for (int q = 0; q < SB; ++q) enx[q] = uni(tg[1 + (ib + SB + q < nT ? ib + SB + q : nT - 1)]);
 #pragma unroll
-                                for (int v = 0; v < RG; ++v) ivn[v] = invB[(size_t)sNext * M0 + rr[v]];
+                                for (int q = 0; q < SB; ++q) {
+                                    const double *rowp = A1 + (size_t)(enx[q] & 255) * N1;
 #pragma unroll
-                                for (int v = 0; v < RG; ++v)
-#pragma unroll
-                                    for (int u = 0; u < CG; ++u) sacc[v][u] += iv[v] * at[u];
-#pragma unroll
-                                for (int u = 0; u < CG; ++u) {
-                                    at[u] = a1[u];
-                                    a1[u] = an[u];
+                                    for (int u = 0; u < CG; ++u) nx[q][u] = rowp[kc[u]];
                                 }
 #pragma unroll
-                                for (int v = 0; v < RG; ++v) iv[v] = ivn[v];
-                                sNext = s2;
-                                s2 = s3;
+                                for (int q = 0; q < SB; ++q) {
+                                    if (ib + q < nT) {
+                                        double ivn[RG];
+                                        const double *nextp = ivp + (size_t)(ib + q + 1 < nT ? ib + q + 1 : ib + q) * RG;
+#pragma unroll
+                                        for (int v = 0; v < RG; ++v) ivn[v] = nextp[v];
+                                        const int rows = ecu[q] >> 8;
+#pragma unroll
+                                        for (int v = 0; v < RG; ++v)
+                                            if (rows & (1 << v)) {
+#pragma unroll
+                                                for (int u = 0; u < CG; ++u) sacc[v][u] += iv[v] * cu[q][u];
+                                            }
+#pragma unroll
+                                        for (int v = 0; v < RG; ++v) iv[v] = ivn[v];
+                                    }
+                                }
+                            };
+                            for (int ib = 0; ib < nT; ib += 2 * SB) {
+                                block(bufA, bufB, ea, eb, ib);
+                                if (ib + SB < nT) block(bufB, bufA, eb, ea, ib + SB);
                             }
                         }
 #pragma unroll
@@ -774,6 +878,9 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                 for (int u = 0; u < CG; ++u)
                     if (on[u]) sdot[kc[u]] = sd[u];
             }
+#ifdef SSQP_PHASE_PROFILE
+            if (tid == 0) (void)__hip_atomic_fetch_add(&g_p1phase[13], __builtin_amdgcn_s_memtime() - yT1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         }
         __syncthreads();
     };
@@ -869,11 +976,34 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
         }
         __syncthreads();
         P1_STAMP(3);  // entering column
-        if (tid == 0) {  // ratio test (first minimum / first maximum over the basic rows, in row order)
+        // ratio test (first minimum / first maximum over the basic rows, in row order).  Many rows: the first wavefront reduces
+        // (value, row) pairs -- candidates first, ties to the smaller row, as in the wavefront kernel -- instead of one thread
+        // walking the rows (21 k cycles per pass at 72 rows)
+        int rtM = 0, rtRow = 0, rtTo = SSQP_DN;
+        double rtLr = 0.0;
+        if (!FEW && tid < 64) {
             const bool fromLower = S1[k] == SSQP_DN;
-            int m = 0, li = -1;
-            double lr = 0.0;
-            int lrow = 0, lto = SSQP_DN;
+            KeyMin cur{INF, 0x7fffffff};
+            bool anyc = false;
+            for (int j = tid; j < M0; j += 64) {
+                const int code = piv[j];
+                const double ratio = blo[j];
+                const bool cand = code != 0;
+                cur = keymin(cur, KeyMin{cand ? (fromLower ? ratio : -ratio) : INF, cand ? j : j + 4096});
+                anyc = anyc || cand;
+            }
+            const bool any = __ballot(anyc) != 0ull;
+            const KeyMin kr = wave_keymin(cur);
+            rtM = any ? 1 : 0;
+            rtRow = any ? kr.ord : 0;
+            rtLr = fromLower ? kr.v : -kr.v;
+            rtTo = piv[rtRow] == 1 ? SSQP_DN : SSQP_UP;
+        }
+        if (tid == 0) {
+            const bool fromLower = S1[k] == SSQP_DN;
+            int m = rtM, li = -1;
+            double lr = rtLr;
+            int lrow = rtRow, lto = rtTo;
             auto consider = [&](int j, int code, double ratio) {
                 if (code == 0) return;
                 const bool better = (m == 0) || (fromLower ? (ratio < lr) : (ratio > lr));
@@ -892,8 +1022,6 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
 #pragma unroll
                 for (int j = 0; j < MC; ++j)
                     if (j < M0) consider(j, cd[j], rt[j]);
-            } else {
-                for (int j = 0; j < M0; ++j) consider(j, piv[j], blo[j]);
             }
             int action = 0, leaveStatus = SSQP_DN, st = 0;  // st: 3 = unbounded
             if (fromLower) {
@@ -931,13 +1059,14 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
         } else if (action == -2) {
             if (tid == 0) S1[k] = SSQP_DN, x[k] = loK;
         } else {
-            if (tid == 0) {
-                const int leaving = basis[action - 1];
-                misc[6] = leaving;
-                nonbasic[k] = 0;
-                nonbasic[leaving] = 1;
-                basis[action - 1] = k;
-                if (FEW) {  // sort(basis) in registers (the basis was sorted before the exchange: one pass each way)
+            if (FEW) {
+                if (tid == 0) {
+                    const int leaving = basis[action - 1];
+                    misc[6] = leaving;
+                    nonbasic[k] = 0;
+                    nonbasic[leaving] = 1;
+                    basis[action - 1] = k;
+                    // sort(basis) in registers (the basis was sorted before the exchange: one pass each way)
                     int bs[MC];
 #pragma unroll
                     for (int a2 = 0; a2 < MC; ++a2) bs[a2] = (a2 < M0) ? basis[a2 < M0 ? a2 : 0] : 0x7fffffff;
@@ -956,19 +1085,53 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
 #pragma unroll
                     for (int a2 = 0; a2 < MC; ++a2)
                         if (a2 < M0) basis[a2] = bs[a2];
-                } else
-                for (int a2 = 1; a2 < M0; ++a2) {  // sort(basis)
-                    const int v = basis[a2];
-                    int c2 = a2 - 1;
-                    while (c2 >= 0 && basis[c2] > v) {
-                        basis[c2 + 1] = basis[c2];
-                        --c2;
-                    }
-                    basis[c2 + 1] = v;
+                }
+            } else if (tid < 64) {
+                // sort(basis) after the exchange: the basis was sorted, one entry leaves (row m), k enters at its rank p among the
+                // others -- every lane computes where its entries of the new order come from (M0 <= 128: two per lane); one
+                // thread's insertion sort was 20 k cycles of dependent LDS round trips at 72 rows
+                const int mrow = action - 1;
+                int o[2];
+                unsigned long long below[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = tid + 64 * h;
+                    o[h] = i < M0 ? basis[i] : 0x7fffffff;
+                    below[h] = __ballot(i < M0 && i != mrow && o[h] < k);
+                }
+                const int pIns = __popcll(below[0]) + __popcll(below[1]);
+                const int leaving = basis[mrow];
+                int nw[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = tid + 64 * h;
+                    const int j = i < pIns ? i : i - 1;                 // index among the entries that stay
+                    const int src = j < mrow ? j : j + 1;               // ... and in the old order
+                    nw[h] = (i == pIns) ? k : basis[i < M0 && i != pIns ? src : 0];
+                }
+                wave_order();   // (every read of the old order is through)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    if (tid + 64 * h < M0) basis[tid + 64 * h] = nw[h];
+                if (tid == 0) {
+                    misc[6] = leaving;
+                    nonbasic[k] = 0;
+                    nonbasic[leaving] = 1;
                 }
             }
             __syncthreads();
-            for (int e = tid; e < M0 * M0; e += NT1) invB[e] = A1[(size_t)(e % M0) * N1 + basis[e / M0]];
+            // (eight elements' column numbers and entries are requested together)
+            for (int e0 = tid; e0 < M0 * M0; e0 += 8 * NT1) {
+                double gv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = e0 + q * NT1 < M0 * M0 ? e0 + q * NT1 : e0;
+                    gv[q] = A1[(size_t)(e % M0) * N1 + basis[e / M0]];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (e0 + q * NT1 < M0 * M0) invB[e0 + q * NT1] = gv[q];
+            }
             __syncthreads();
             P1_STAMP(5);  // basis sort + gather
             P1_COUNT(15);
@@ -1233,7 +1396,7 @@ size_t phase1_ws_ints(int N, int M, int J) {
 }
 size_t phase1_lds_bytes(int M, int J) {  // without the N1-vectors
     const size_t M0 = (size_t)(M + J);
-    return (2 * M0 * M0 + 8 * M0 + 4 + p1::XB_CHUNK * M0) * 8 + (3 * M0 + 4 + 8) * 4 + 64;
+    return (2 * M0 * M0 + (M0 > 12 ? 15 : 8) * M0 + 4 + p1::XB_CHUNK * M0) * 8 + (3 * M0 + 4 + 8) * 4 + 64;
 }
 // with x, colnorm, sdot, S1, nonbasic of up to N1x = 2N + J + M0 columns in LDS
 static size_t phase1_lds_bytes_vec(int N, int M, int J) {
