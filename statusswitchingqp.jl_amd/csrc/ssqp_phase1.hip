@@ -15,6 +15,7 @@
 // Workspace per QP in global memory (76 KB at N = 512, M0 = 11): the LP matrix A1 (M0 x N1, row-major) and the
 // N1-vectors; the host's Y = invB * A[:, nonbasic] is never stored (see refreshY); LDS holds invB, the basis matrix
 // being inverted and the M0-vectors.
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -25,7 +26,9 @@
 namespace ssqp {
 namespace p1 {
 
-constexpr int NT1 = 256;
+constexpr int NT1 = 256;   // threads per workgroup, few rows
+template <bool BIG> constexpr int NTB = BIG ? 512 : NT1;   // many rows: two wavefronts per SIMD (what bounds that build is
+                                                            // instruction issue: a lone wavefront issues once in ~4.5 cycles)
 constexpr int XB_CHUNK = 32;   // columns of the xb sum whose products are formed together (staged in LDS)
 constexpr double INF = __builtin_huge_val();
 
@@ -54,6 +57,7 @@ static __device__ unsigned long long g_p1phase[16];
 #endif
 
 // block-wide (value, index) maximum with the FIRST maximum winning (smallest index on ties); all threads get it
+template <int NT>
 __device__ __forceinline__ void block_first_max(double &v, int &idx, double *rv, int *ri) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     {   // inside the wavefront: DPP steps (the first maximum of v = the first minimum of -v)
@@ -68,7 +72,7 @@ __device__ __forceinline__ void block_first_max(double &v, int &idx, double *rv,
     __syncthreads();
     v = rv[0];
     idx = ri[0];
-    for (int w = 1; w < NT1 / 64; ++w) {
+    for (int w = 1; w < NT / 64; ++w) {
         const bool take = (rv[w] > v) || (rv[w] == v && ri[w] < idx);
         v = take ? rv[w] : v;
         idx = take ? ri[w] : idx;
@@ -126,6 +130,7 @@ __device__ __forceinline__ void wave_order() {
 //   * columns of the inverse: three lanes of one wavefront per column, 21 columns per wavefront, no barrier between steps; a
 //     forward step whose L column is zero is not walked at all (a bit mask in scalar registers), neither is a step at which
 //     none of the wavefront's columns has a nonzero entry, and a backward step whose U column is empty is the division only.
+template <int NT>
 __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double *vec, int *piv, int n, int *flag) {
     const int lane = tid & 63;
     int *Lnz = reinterpret_cast<int *>(vec), *Unz = Lnz + n, *hasU = Lnz + 2 * n;   // (vec: 2 n doubles = 4 n ints)
@@ -238,7 +243,7 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
             // listed rows ri + 16 m of the listed columns cj + 16 g, five rows per LDS round trip
             const int cj = tid >> 4, ri = tid & 15;
             const double *colk = a + (size_t)k * n;
-            for (int jj = cj; jj < nU; jj += NT1 / 16) {
+            for (int jj = cj; jj < nU; jj += NT / 16) {
                 double *colj = a + (size_t)Unz[jj] * n;
                 const double uj = colj[k];
                 for (int i0 = ri; i0 < nL; i0 += 16 * 5) {
@@ -268,10 +273,12 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
     const unsigned long long luT1 = __builtin_amdgcn_s_memtime();
     if (tid == 0) (void)__hip_atomic_fetch_add(&g_p1phase[10], luT1 - luT0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
-    {
+    auto columns = [&](auto lpcTag) {
+        // (LPC lanes per column, lane q of them takes the rows i = q mod LPC; 64 / LPC columns per wavefront)
+        constexpr int LPC = decltype(lpcTag)::value, CPW = 64 / LPC;
         const int wv = tid >> 6;
-        const int c = wv * 21 + lane / 3, q = lane % 3;
-        const bool mine = lane < 63 && c < n;
+        const int c = wv * CPW + lane / LPC, q = lane % LPC;
+        const bool mine = lane < CPW * LPC && c < n;
         // the steps with a nonzero L column / a nonempty U column, as bit masks (steps 0 .. 63, 64 .. 127)
         unsigned long long fwd[2], upd[2];
 #pragma unroll
@@ -287,24 +294,24 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
                 const int pk = piv[k];
                 if (pk != k) pos = (pos == k) ? pk : ((pos == pk) ? k : pos);
             }
-            for (int i = q; i < n; i += 3) xc[i] = (i == pos) ? 1.0 : 0.0;
+            for (int i = q; i < n; i += LPC) xc[i] = (i == pos) ? 1.0 : 0.0;
         }
         wave_order();
         // x[i] -= f[i] * t for this lane's rows of lo .. hi - 1, eight per LDS round trip (the compiler cannot tell that the
         // stores to x do not alias the factors and would wait for every element's own read - modify - write)
         auto axpy = [&](const double *f, int lo, int hi, double t) {
-            int first = lo + ((q - lo) % 3 + 3) % 3;   // the first row >= lo with i = q mod 3
-            for (int i0 = first; i0 < hi; i0 += 24) {
+            int first = lo + ((q - lo) % LPC + LPC) % LPC;   // the first row >= lo with i = q mod LPC
+            for (int i0 = first; i0 < hi; i0 += 8 * LPC) {
                 double fv[8], xv[8];
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
-                    const int i = i0 + 3 * m < hi ? i0 + 3 * m : i0;
+                    const int i = i0 + LPC * m < hi ? i0 + LPC * m : i0;
                     fv[m] = f[i];
                     xv[m] = xc[i];
                 }
 #pragma unroll
                 for (int m = 0; m < 8; ++m)
-                    if (i0 + 3 * m < hi) xc[i0 + 3 * m] = xv[m] - fv[m] * t;
+                    if (i0 + LPC * m < hi) xc[i0 + LPC * m] = xv[m] - fv[m] * t;
             }
         };
         // forward: x[i] -= L(i, k) x[k]  for i > k  (the host's "t != 0" guard only skips zeros; so does the mask)
@@ -335,34 +342,38 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
                 const double t = xk / a[(size_t)k * n + k];
                 wave_order();   // (the three lanes have read x[k])
                 if (mine) {
-                    if (k % 3 == q) xc[k] = t;
+                    if (k % LPC == q) xc[k] = t;
                     axpy(a + (size_t)k * n, 0, k, t);
                 }
                 wave_order();
             }
         }
         if (mine) {
-            for (int i0 = q; i0 < n; i0 += 24) {
+            for (int i0 = q; i0 < n; i0 += 8 * LPC) {
                 double xv[8], dv[8];
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
-                    const int i = i0 + 3 * m < n ? i0 + 3 * m : i0;
+                    const int i = i0 + LPC * m < n ? i0 + LPC * m : i0;
                     xv[m] = xc[i];
                     dv[m] = a[(size_t)i * n + i];
                 }
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
-                    const int i = i0 + 3 * m;
+                    const int i = i0 + LPC * m;
                     if (i < n && !((upd[i >> 6] >> (i & 63)) & 1ull) && xv[m] != 0.0) xc[i] = xv[m] / dv[m];
                 }
             }
         }
-    }
+    };
+    // (three lanes per column serve 21 columns per wavefront: 84 with four wavefronts, 168 with eight; with eight wavefronts and
+    //  n <= 80, six lanes per column halve a step's rows per lane)
+    if (NT >= 512 && n <= 80) columns(std::integral_constant<int, 6>{});
+    else columns(std::integral_constant<int, 3>{});
     __syncthreads();
 #ifdef SSQP_PHASE_PROFILE
     if (tid == 0) (void)__hip_atomic_fetch_add(&g_p1phase[11], __builtin_amdgcn_s_memtime() - luT1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
-    for (int e = tid; e < n * n; e += NT1) {
+    for (int e = tid; e < n * n; e += NT) {
         const int cc = e / n, i = e - cc * n;
         a[e] = x[(size_t)cc * xs + i];
     }
@@ -521,6 +532,7 @@ struct P1Params {
 // BIG: the build for many rows (M0 > 12), one workgroup per CU: twice the registers, spent on wider tiles of the Y . c refresh
 template <bool BIG>
 __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob, unsigned char *smem) {
+    constexpr int NT1 = NTB<BIG>;   // (this build's threads per workgroup)
     const int tid = threadIdx.x;
     P1_DECL;
     const int N = P.N, M = P.M, J = P.J, M0 = M + J;
@@ -543,12 +555,12 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
     double *pv = xb + M0;
     double *acc = pv + M0;
     double *blo = acc + M0, *bhi = blo + M0;       // bounds of the basic variables by row
-    double *redv = bhi + M0;                       // 4
-    double *terms = redv + 4;                      // XB_CHUNK x M0: products Y[r, k] x[k] of the xb sum, a chunk of columns at a time
+    double *redv = bhi + M0;                       // 4 (many rows: 12 -- one per wavefront for the block maximum, [8]: the leaving bound)
+    double *terms = redv + (BIG ? 12 : 4);                      // XB_CHUNK x M0: products Y[r, k] x[k] of the xb sum, a chunk of columns at a time
     int *basis = reinterpret_cast<int *>(terms + (size_t)XB_CHUNK * M0);  // M0
     int *piv = basis + M0;                         // 2 M0 (row swaps of the LU, then the positions of the permuted unit vectors)
-    int *redi = piv + 2 * M0;                      // 4
-    int *misc = redi + 4;                          // [0] count, [1] flag, [2] action, [3] leaveStatus, [4] n free, [5] n upperOnly
+    int *redi = piv + 2 * M0;                      // 4 (many rows: 8)
+    int *misc = redi + (BIG ? 8 : 4);                          // [0] count, [1] flag, [2] action, [3] leaveStatus, [4] n free, [5] n upperOnly
 
     // ---- free / upper-only variables (SSQP.jl:484-509), ascending lists
     int *iw = P.wsInt + (size_t)prob * P.wsIntStride;
@@ -732,7 +744,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
             // per refresh at M0 = 72, 80 % of cfg5's Phase-1).  Per element the sums keep the host's order: t ascending inside
             // a row, rows ascending.
 #ifdef SSQP_PHASE_PROFILE
-            const unsigned long long yT0 = __builtin_amdgcn_s_memtime();
+            unsigned long long ySet = 0, yLoop = 0, yEpi = 0;
 #endif
             int *art = piv;   // (the LU's integer scratch is idle here)
             const int nArt = compact_columns(tid, M0, art, &misc[0], [&](int r) { return basis[r] >= N0; });
@@ -777,10 +789,6 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                 }
             }
             __syncthreads();
-#ifdef SSQP_PHASE_PROFILE
-            const unsigned long long yT1 = __builtin_amdgcn_s_memtime();
-            if (tid == 0) (void)__hip_atomic_fetch_add(&g_p1phase[12], yT1 - yT0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
             for (int kb = 0; kb < N1; kb += CG * NT1) {
                 int kc[CG];
                 bool on[CG];
@@ -797,6 +805,10 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                 for (int u = 0; u < CG; ++u) sd[u] = 0.0;
                 if (anyOn) {
                     for (int g0 = 0; g0 < nArt; g0 += RG) {
+#ifdef SSQP_PHASE_PROFILE
+                        const unsigned long long yA = __builtin_amdgcn_s_memtime();
+                        unsigned long long yB = yA, yC = yA;
+#endif
                         const int *tg = tl + (g0 / RG) * (M0 + 1);
                         const int nT = tg[0];
                         int rr[RG];
@@ -821,7 +833,10 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                             //  packed (RG contiguous doubles per listed step, one address), the LP's entries through a scalar
                             //  row base plus the thread's column offset, in BLOCKS of four steps requested one block ahead, and
                             //  the two register sets change roles instead of being copied)
-                            constexpr int SB = 4;
+#ifndef P1_Y_SB
+#define P1_Y_SB 4
+#endif
+                            constexpr int SB = P1_Y_SB;
                             const double *ivp = IV + (size_t)(g0 / RG) * M0 * RG;
                             int ea[SB], eb[SB];
                             double bufA[SB][CG], bufB[SB][CG], iv[RG];
@@ -851,27 +866,66 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                                         const double *nextp = ivp + (size_t)(ib + q + 1 < nT ? ib + q + 1 : ib + q) * RG;
 #pragma unroll
                                         for (int v = 0; v < RG; ++v) ivn[v] = nextp[v];
-                                        const int rows = ecu[q] >> 8;
+                                        int rows = ecu[q] >> 8;
+#ifdef P1_Y_FULLKIND
+                                        // (a step most rows take part in runs all of them without the eight tests: a product with
+                                        //  an exact zero adds +-0.0 and changes no bit; only the steps of one or two rows -- the
+                                        //  diagonals of the artificial rows -- pay for being picked out)
+                                        if (__builtin_popcount(rows) >= P1_Y_FULLKIND) rows = (1 << RG) - 1;
+                                        if (rows == (1 << RG) - 1) {
+#pragma unroll
+                                            for (int v = 0; v < RG; ++v) {
+                                                double p0 = iv[v] * cu[q][0], p1 = iv[v] * cu[q][1], p2 = iv[v] * cu[q][2], p3 = iv[v] * cu[q][3];
+                                                asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+                                                sacc[v][0] += p0;
+                                                sacc[v][1] += p1;
+                                                sacc[v][2] += p2;
+                                                sacc[v][3] += p3;
+                                            }
+                                        } else
+#endif
 #pragma unroll
                                         for (int v = 0; v < RG; ++v)
                                             if (rows & (1 << v)) {
-#pragma unroll
-                                                for (int u = 0; u < CG; ++u) sacc[v][u] += iv[v] * cu[q][u];
+                                                // (the four products first, then the four sums: back to back, every sum would
+                                                //  wait out its own product's latency -- there is no second wavefront on the SIMD)
+                                                static_assert(CG == 4, "the product / sum interleave below is written for four columns");
+                                                double p0 = iv[v] * cu[q][0], p1 = iv[v] * cu[q][1], p2 = iv[v] * cu[q][2], p3 = iv[v] * cu[q][3];
+                                                asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+                                                sacc[v][0] += p0;
+                                                sacc[v][1] += p1;
+                                                sacc[v][2] += p2;
+                                                sacc[v][3] += p3;
                                             }
 #pragma unroll
                                         for (int v = 0; v < RG; ++v) iv[v] = ivn[v];
                                     }
                                 }
                             };
+#ifdef SSQP_PHASE_PROFILE
+                            yB = __builtin_amdgcn_s_memtime();
+#endif
                             for (int ib = 0; ib < nT; ib += 2 * SB) {
                                 block(bufA, bufB, ea, eb, ib);
                                 if (ib + SB < nT) block(bufB, bufA, eb, ea, ib + SB);
                             }
+#ifdef SSQP_PHASE_PROFILE
+                            yC = __builtin_amdgcn_s_memtime();
+#endif
                         }
 #pragma unroll
                         for (int v = 0; v < RG; ++v)
 #pragma unroll
                             for (int u = 0; u < CG; ++u) sd[u] += sacc[v][u] * wt[v];
+#ifdef SSQP_PHASE_PROFILE
+                        {
+                            asm volatile("" : "+v"(sd[0]));
+                            const unsigned long long yD = __builtin_amdgcn_s_memtime();
+                            ySet += yB - yA;
+                            yLoop += yC - yB;
+                            yEpi += yD - yC;
+                        }
+#endif
                     }
                 }
 #pragma unroll
@@ -879,7 +933,11 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                     if (on[u]) sdot[kc[u]] = sd[u];
             }
 #ifdef SSQP_PHASE_PROFILE
-            if (tid == 0) (void)__hip_atomic_fetch_add(&g_p1phase[13], __builtin_amdgcn_s_memtime() - yT1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                (void)__hip_atomic_fetch_add(&g_p1phase[9], ySet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                (void)__hip_atomic_fetch_add(&g_p1phase[12], yLoop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                (void)__hip_atomic_fetch_add(&g_p1phase[13], yEpi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
 #endif
         }
         __syncthreads();
@@ -918,7 +976,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
             }
         }
         P1_STAMP(1);  // pricing
-        block_first_max(best, bidx, redv, redi);
+        block_first_max<NT1>(best, bidx, redv, redi);
         P1_STAMP(2);  // block maximum
         if (bidx == 0x7fffffff) break;  // no improving candidate: optimal
         const int k = bidx;
@@ -1042,7 +1100,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                 else action = lrow + 1, leaveStatus = lto;
             }
             (void)li;
-            redv[3] = (leaveStatus == SSQP_DN) ? acc[lrow] : bhi[lrow];  // (a pivot: the bound the leaving variable goes to)
+            redv[BIG ? 8 : 3] = (leaveStatus == SSQP_DN) ? acc[lrow] : bhi[lrow];  // (a pivot: the bound the leaving variable goes to)
             misc[2] = action;
             misc[3] = leaveStatus;
             misc[1] = st;
@@ -1144,7 +1202,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                 __syncthreads();
                 okLu = misc[1] != 0;
             } else {
-                okLu = invert_lu(tid, invB, Bm, terms, piv, M0, &misc[1]);   // (terms: idle here, >= 2 M0 doubles)
+                okLu = invert_lu<NT1>(tid, invB, Bm, terms, piv, M0, &misc[1]);   // (terms: idle here, >= 2 M0 doubles)
             }
             if (!okLu) {  // lu() of the reference throws (Simplex.jl:590)
                 status = -1;
@@ -1154,7 +1212,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                 const int leaving = misc[6], leaveStatus = misc[3];
                 S1[k] = SSQP_IN;
                 S1[leaving] = leaveStatus;
-                x[leaving] = redv[3];
+                x[leaving] = redv[BIG ? 8 : 3];
             }
             P1_STAMP(6);  // inv(lu(B))
             refreshY();
@@ -1174,8 +1232,8 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                 // cycles per pass on cfg5 -- and thread (g, r) forms row r of the columns g, g + G, ... of the chunk: one entry
                 // of inv(B) is read per step for up to XBC columns, the LP's entries are broadcast reads.  Per element the
                 // sum runs over t ascending, as refreshY forms Y[r, k].
-                constexpr int XBC = 16;
-                const int G = NT1 / M0 < 4 ? (NT1 / M0 < 2 ? 2 : NT1 / M0) : 4;   // column groups (M0 <= 128)
+                constexpr int XBC = 8;                                             // (XB_CHUNK = 32 columns = 4 groups x 8)
+                const int G = 4;                                                   // column groups: 4 M0 <= 512 threads (M0 <= 128)
                 const int chunk = XB_CHUNK < M0 ? XB_CHUNK : M0;                   // (chunk x M0 doubles fit the scratch)
                 const int g = tid / M0, r = tid - g * M0;
                 double *Ac = Bm;                                                   // column t of the chunk at t * M0
@@ -1374,7 +1432,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
 }
 
 template <bool BIG>
-__global__ __launch_bounds__(NT1, BIG ? 2 : 4) void ssqp_phase1_kernel(P1Params P) {  // (four workgroups per CU: 1,024 QPs resident)
+__global__ __launch_bounds__(NTB<BIG>, BIG ? 1 : 4) void ssqp_phase1_kernel(P1Params P) {  // (four workgroups per CU: 1,024 QPs resident)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // one QP per workgroup; on a list (what the wavefront kernel left) a bounded grid strides over it
     const int n = P.list ? (int)*P.listCount : P.nprob;
@@ -1396,7 +1454,7 @@ size_t phase1_ws_ints(int N, int M, int J) {
 }
 size_t phase1_lds_bytes(int M, int J) {  // without the N1-vectors
     const size_t M0 = (size_t)(M + J);
-    return (2 * M0 * M0 + (M0 > 12 ? 15 : 8) * M0 + 4 + p1::XB_CHUNK * M0) * 8 + (3 * M0 + 4 + 8) * 4 + 64;
+    return (2 * M0 * M0 + (M0 > 12 ? 15 : 8) * M0 + (M0 > 12 ? 12 : 4) + p1::XB_CHUNK * M0) * 8 + (3 * M0 + (M0 > 12 ? 8 : 4) + 8) * 4 + 64;
 }
 // with x, colnorm, sdot, S1, nonbasic of up to N1x = 2N + J + M0 columns in LDS
 static size_t phase1_lds_bytes_vec(int N, int M, int J) {
@@ -1431,7 +1489,7 @@ hipError_t launch_phase1(int nprob, int N, int M, int J, const double *A, const 
     if (M + J > 12) {   // many rows: the build with the wide refresh tiles
         hipError_t e = allow_full_lds(reinterpret_cast<const void *>(&p1::ssqp_phase1_kernel<true>), &ldsSetBig);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(p1::ssqp_phase1_kernel<true>, dim3(grid), dim3(p1::NT1), lds, stream, P);
+        hipLaunchKernelGGL(p1::ssqp_phase1_kernel<true>, dim3(grid), dim3(p1::NTB<true>), lds, stream, P);
         return hipGetLastError();
     }
     hipError_t e = allow_full_lds(reinterpret_cast<const void *>(&p1::ssqp_phase1_kernel<false>), &ldsSet);

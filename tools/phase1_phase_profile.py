@@ -30,7 +30,8 @@ for i, n in enumerate(names):
 if out[10] or out[11]:
     print("  inv(lu(B)) of the many-rows build: elimination %.0f, columns of the inverse %.0f cycles per basis change" % (
         out[10] / max(bc, 1), out[11] / max(bc, 1)))
-    print("  Y.c refresh of the many-rows build: lists %.0f, column loop %.0f cycles per refresh" % (out[12] / max(bc + 1, 1), out[13] / max(bc + 1, 1)))
+    print("  Y.c refresh of the many-rows build, column loop per refresh: group set-up + first loads %.0f, step blocks %.0f, row sums %.0f cycles" % (
+        out[9] / max(bc + 1, 1), out[12] / max(bc + 1, 1), out[13] / max(bc + 1, 1)))
 
 # ---- the one-wavefront-per-QP kernel (the default where it applies): its own stamps
 lib.ssqp_debug_phase1_wave_phases.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
