@@ -133,9 +133,11 @@ __device__ __forceinline__ void wave_order() {
 template <int NT>
 __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double *vec, int *piv, int n, int *flag) {
     const int lane = tid & 63;
-    int *Lnz = reinterpret_cast<int *>(vec), *Unz = Lnz + n, *hasU = Lnz + 2 * n;   // (vec: 2 n doubles = 4 n ints)
-    int *stepInfo = piv + n;                                                         // nL | nU << 8 of step k
-    double *rinv = x;                                                                // 1 / pivot of step k (x is idle until the columns start)
+    // (vec: 4 n doubles = 8 n ints)
+    int *Lnz = reinterpret_cast<int *>(vec), *Unz = Lnz + n, *hasU = Lnz + 2 * n, *physOf = Lnz + 3 * n, *mv = Lnz + 4 * n;
+    int *ctrl = Lnz + 5 * n;   // [0] the step the workgroup takes up (n: none is left), [1] where the run started, [2] rows to move
+    double *rinvp = reinterpret_cast<double *>(Lnz + ((5 * n + 8 + 1) & ~1));   // 1 / pivot of the step taken up
+    int *stepInfo = piv + n;                                                     // nL | nU << 8 of step k
 #ifdef SSQP_PHASE_PROFILE
     const unsigned long long luT0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -143,59 +145,60 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
         for (int j = lane; j < n; j += 64) hasU[j] = 0;
         wave_order();
     }
-    int *ctrl = Lnz + 3 * n;   // [0]: the step the workgroup takes up after the barrier (n: none is left)
     for (int k = 0;;) {
         if (tid < 64) {
-            // wavefront 0 walks the steps from k on.  A step whose L column is zero updates nothing: its whole effect is the
-            // exchange of two rows, which this wavefront does itself (two elements per column) before it looks at the next
-            // column -- no barrier until a step with a nonzero L column turns up, and most steps have none
+            // Wavefront 0 walks the steps from k on.  A step whose L column is zero updates nothing: its whole effect is the
+            // exchange of two rows.  During a run of such steps nothing in the matrix changes, so the exchange is only NOTED --
+            // every lane keeps the logical position of its two physical rows in registers, the pivot search orders its
+            // candidates by logical row -- and a step costs one column read and one wavefront reduction, no LDS write in the
+            // dependent chain and no barrier.  When a step with a nonzero L column turns up (or the last step is through)
+            // the workgroup moves the rows that changed places, once, and marks the U rows of the run.
+            const int r0 = lane, r1 = lane + 64;
+            int lg0 = r0, lg1 = r1;
+            bool anySwap = false, ok = true, dense = false;
             int kk = k;
-            bool ok;
+            double c0 = r0 < n ? a[(size_t)kk * n + r0] : 0.0, c1 = r1 < n ? a[(size_t)kk * n + r1] : 0.0;
             for (;;) {
-                const double *colk = a + (size_t)kk * n;
-                double best = -1.0;   // the FIRST largest |a(i, kk)|, i = kk .. n - 1 (the host's strict ">" scan)
-                int bi = 0x7fffffff;
-                for (int i = kk + lane; i < n; i += 64) {
-                    const double v = fabs(colk[i]);
-                    if (v > best) best = v, bi = i;   // (ascending i inside the lane)
-                }
-                const KeyMin km = wave_keymin(KeyMin{-best, bi});
-                ok = !(km.v == 0.0 || km.ord >= n);   // (-best == -0.0: the whole column is zero; no order: nothing but NaN)
+                const bool v0 = r0 < n && lg0 >= kk, v1 = r1 < n && lg1 >= kk;
+                // the FIRST largest |a(i, kk)| over the logical rows i = kk .. n - 1 (the host's strict ">" scan)
+                const KeyMin cur = keymin(KeyMin{v0 ? -fabs(c0) : 1.0, v0 ? lg0 : 0x7fffffff}, KeyMin{v1 ? -fabs(c1) : 1.0, v1 ? lg1 : 0x7fffffff});
+                const KeyMin km = wave_keymin(cur);
+                ok = !(km.v == 0.0 || km.ord >= n);   // (-0.0: the whole column is zero; no order: nothing but NaN)
                 if (!ok) break;
                 const int p = km.ord;
-                int nL = 0, nU = 0;
-                for (int ib = kk + 1; ib < n; ib += 64) {  // rows of the L column that are not exactly zero (positions after the swap)
-                    const int i = ib + lane;
-                    const bool f = i < n && colk[i == p ? kk : i] != 0.0;
-                    const unsigned long long m = __ballot(f);
-                    if (f) Lnz[nL + __popcll(m & ((1ull << lane) - 1ull))] = i;
-                    nL += __popcll(m);
-                }
-                if (nL == 0) {
-                    for (int jb = 0; jb < n; jb += 64) {
-                        const int j = jb + lane;
-                        double *colj = a + (size_t)(j < n ? j : 0) * n;
-                        const double vk = colj[kk], vp = colj[p];
-                        if (j < n && j > kk && vp != 0.0) hasU[j] = 1;   // (row p before the swap = the U row)
-                        if (j < n && p != kk) {
-                            colj[kk] = vp;
-                            colj[p] = vk;
-                        }
+                const bool l0 = v0 && lg0 != p && c0 != 0.0, l1 = v1 && lg1 != p && c1 != 0.0;   // nonzeros of the L column
+                const unsigned long long m0 = __ballot(l0), m1 = __ballot(l1);
+                if ((m0 | m1) == 0ull) {
+                    if (p != kk) {
+                        lg0 = lg0 == kk ? p : (lg0 == p ? kk : lg0);
+                        lg1 = lg1 == kk ? p : (lg1 == p ? kk : lg1);
+                        anySwap = true;
                     }
                     if (lane == 0) {
                         piv[kk] = p;
                         stepInfo[kk] = 0;
                     }
-                    wave_order();
                     if (++kk == n) break;
+                    c0 = r0 < n ? a[(size_t)kk * n + r0] : 0.0;
+                    c1 = r1 < n ? a[(size_t)kk * n + r1] : 0.0;
                     continue;
                 }
-                for (int jb = kk + 1; jb < n; jb += 64) {  // columns of the U row (row p before the swap) that are not exactly zero
+                // a step with a nonzero L column: its lists in LOGICAL rows (what is physical once the rows have been moved),
+                // at the positions after this step's own exchange of kk and p
+                dense = true;
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (l0) Lnz[__popcll(m0 & below)] = lg0 == kk ? p : lg0;
+                if (l1) Lnz[__popcll(m0) + __popcll(m1 & below)] = lg1 == kk ? p : lg1;
+                const int nL = __popcll(m0) + __popcll(m1);
+                const unsigned long long h0 = __ballot(r0 < n && lg0 == p);
+                const int pPhys = h0 ? __builtin_ctzll(h0) : 64 + __builtin_ctzll(__ballot(r1 < n && lg1 == p));
+                int nU = 0;
+                for (int jb = kk + 1; jb < n; jb += 64) {  // columns of the U row (the pivot's row) that are not exactly zero
                     const int j = jb + lane;
-                    const bool f = j < n && a[(size_t)j * n + p] != 0.0;
+                    const bool f = j < n && a[(size_t)j * n + pPhys] != 0.0;
                     const unsigned long long m = __ballot(f);
                     if (f) {
-                        Unz[nU + __popcll(m & ((1ull << lane) - 1ull))] = j;
+                        Unz[nU + __popcll(m & below)] = j;
                         hasU[j] = 1;
                     }
                     nU += __popcll(m);
@@ -203,19 +206,53 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
                 if (lane == 0) {
                     piv[kk] = p;
                     stepInfo[kk] = nL | (nU << 8);
-                    rinv[kk] = 1.0 / colk[p];
+                    *rinvp = 1.0 / a[(size_t)kk * n + pPhys];
                 }
                 break;
+            }
+            int nMv = 0;
+            if (ok && anySwap) {  // where every logical row lies, and the list of those that have to move
+                if (r0 < n) physOf[lg0] = r0;
+                if (r1 < n) physOf[lg1] = r1;
+                const bool f0 = r0 < n && lg0 != r0, f1 = r1 < n && lg1 != r1;
+                const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (f0) mv[__popcll(m0 & below)] = lg0;
+                if (f1) mv[__popcll(m0) + __popcll(m1 & below)] = lg1;
+                nMv = __popcll(m0) + __popcll(m1);
             }
             if (lane == 0) {
                 *flag = ok ? 1 : 0;
                 ctrl[0] = kk;
+                ctrl[1] = k;
+                ctrl[2] = nMv;
+                ctrl[3] = dense ? 1 : 0;
             }
         }
         __syncthreads();
         if (!*flag) return false;
+        const int k0 = k, nMv = ctrl[2];
+        const bool dense = ctrl[3] != 0;
         k = ctrl[0];
-        if (k >= n) break;
+        // the U rows of the run's steps k0 .. k - 1 (logical row i lies at physOf[i] while rows wait to be moved): a column with
+        // an entry in one of them has a nonempty U column
+        for (int e = tid; e < (k - k0) * n; e += NT) {
+            const int di = e / n, j = e - di * n, i = k0 + di;
+            if (j > i && a[(size_t)j * n + (nMv ? physOf[i] : i)] != 0.0) hasU[j] = 1;
+        }
+        if (nMv) {  // the rows that changed places, through the scratch (read everything, barrier, write)
+            for (int e = tid; e < nMv * n; e += NT) {
+                const int m = e / n, j = e - m * n;
+                x[e] = a[(size_t)j * n + physOf[mv[m]]];
+            }
+            __syncthreads();
+            for (int e = tid; e < nMv * n; e += NT) {
+                const int m = e / n, j = e - m * n;
+                a[(size_t)j * n + mv[m]] = x[e];
+            }
+        }
+        if (!dense) break;   // (the last step is through; the barrier before the columns of the inverse orders the writes above)
+        __syncthreads();
         const int p = piv[k], info = stepInfo[k];
         // rows k and p change places in every column but k (thread j < 128 takes column j); column k: a(i, k) = a(i', k) / pivot
         // for i > k with i' the row the swap brings to i, and the pivot itself moves to (k, k) (thread 128 + i - k - 1)
@@ -230,7 +267,7 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
             const int i = k + 1 + (tid - 128);
             if (i < n) {
                 double *colk = a + (size_t)k * n;
-                const double r = rinv[k];
+                const double r = *rinvp;
                 const double src = colk[i == p ? k : i], pv = colk[p];
                 colk[i] = src * r;               // a(i, k) *= 1 / a(k, k)
                 if (i == p) colk[k] = pv;
@@ -238,7 +275,7 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
         }
         __syncthreads();
         const int nL = info & 255, nU = info >> 8;
-        if (nL > 0 && nU > 0) {
+        if (nU > 0) {
             // a(i, j) -= a(i, k) * a(k, j) over the listed rows and columns: thread (cj = tid >> 4, ri = tid & 15) takes the
             // listed rows ri + 16 m of the listed columns cj + 16 g, five rows per LDS round trip
             const int cj = tid >> 4, ri = tid & 15;
@@ -265,6 +302,7 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
         }
         if (++k >= n) break;
     }
+    __syncthreads();
     // columns of the inverse: L U x_c = P e_c, THREE lanes of one wavefront per column (lane q takes the rows i = q mod 3), 21
     // columns per wavefront: between two steps the three only need the wavefront's own LDS ordering, no barrier.  P e_c: the
     // host applies the row swaps to e_c in order; the permuted unit vector has its 1 where that sequence of swaps sends c
