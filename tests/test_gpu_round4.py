@@ -158,3 +158,35 @@ def test_lean_builds_without_statistics_give_the_same_results(pkg, orc, name, np
     assert not rl["stats"]["iters"].any()                      # (the lean launch wrote no statistics)
     assert np.array_equal(rl["z"], ra["z"]) and np.array_equal(rl["S"], ra["S"]) and np.array_equal(rl["status"], ra["status"])
     assert_parity(rl["z"], rl["S"], rl["status"], zo, So, sto)
+
+
+@pytest.mark.parametrize("shape", [(48, 3, 10), (64, 2, 30), (96, 4, 60), (80, 4, 80)])
+@pytest.mark.parametrize("kind", ["plain", "some_free", "infeasible"])
+def test_phase1_many_rows_build(pkg, orc, shape, kind):
+    """the many-rows build of the workgroup Phase-1 kernel (M + J > 12: 512 threads, sparsity-aware inv(lu(B)) with the
+    logical row map, listed steps of the Y.c refresh, staged xb) at 13, 32, 64 and 84 rows -- one and two 64-lane chunks
+    per column, three and six lanes per column of the inverse -- bit for bit the host stage's (x0, S0, status), which the
+    CPU suite pins to the oracle"""
+    N, M, J = shape
+    ub = 0.0 if kind == "some_free" else 4.0 / N
+    cfg = pkg.GenConfig(N, M, J, 2 * N, 1e-3, ub, 1.0, 0.2)
+    prob = pkg.generate_batch(cfg, 6, 1000 + N + J)
+    if kind == "infeasible":
+        prob["u"][:] = 0.5 / N
+    elif kind == "some_free":
+        prob["d"][:, ::7] = -np.inf
+        prob["u"][:, ::7] = np.inf
+        prob["u"][:, 1::7] = 4.0 / N
+        prob["d"][:, 1::7] = 0.0
+        prob["u"][:, 2::7] = 4.0 / N
+    xh, Sh, sth = pkg.phase1_batch(prob)
+    xo, So, sto = orc.initQP_batch(prob["A"], prob["G"], prob["b"], prob["g"], prob["d"], prob["u"])
+    assert np.array_equal(sth, sto) and np.array_equal(Sh, So) and np.array_equal(xh, xo)
+    P = prob["q"].shape[0]
+    db = pkg.DeviceBatch(prob, np.zeros((P, N + J), dtype=np.int32), np.zeros((P, N)))
+    st = db.phase1()
+    db.torch.cuda.synchronize()
+    assert np.array_equal(st.cpu().numpy(), sth), (shape, kind, st.cpu().numpy(), sth)
+    assert np.array_equal(db.S0.cpu().numpy(), Sh) and np.array_equal(db.x0.cpu().numpy(), xh), (shape, kind)
+    if kind == "infeasible":
+        assert (sth == 0).all()
