@@ -11,7 +11,7 @@ F='^make\|amdgpu.ids'
   echo "### Phase-1 kernels, cfg4 x 1024 (tools/phase1_phase_profile.py, diagnostic build): workgroup kernel, then the one-wavefront-per-QP kernel"
   SSQP_PROF_LIB=$PROF timeout -k 10 300 python tools/phase1_phase_profile.py cfg4 1024 2>&1 | grep -v "$F"
   echo; echo "### Phase-1 workgroup kernel (many-rows build), cfg5 x 1"
-  SSQP_PROF_LIB=$PROF timeout -k 10 300 python tools/phase1_phase_profile.py cfg5 1 2>&1 | grep -v "$F" | head -12
+  SSQP_PROF_LIB=$PROF timeout -k 10 300 python tools/phase1_phase_profile.py cfg5 1 2>&1 | grep -v "$F" | head -16
   echo; echo "### wavefront kernel, four-per-CU build, cfg4 x 1024 (tools/wave_phase_profile.py)"
   SSQP_PROF_LIB=$PROF timeout -k 10 300 python tools/wave_phase_profile.py cfg4 1024 2>&1 | grep -v "$F"
   echo; echo "### big-factor build from the first pass, cfg3 x 1024 (wave_kernel=2)"
