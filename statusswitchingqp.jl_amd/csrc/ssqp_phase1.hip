@@ -1,4 +1,7 @@
-// ssqp_phase1.hip -- gfx950: Phase-1 of solveQP(Q) for a BATCH of QPs on the GPU, one 256-thread workgroup per QP.
+// ssqp_phase1.hip -- gfx950: Phase-1 of solveQP(Q) for a BATCH of QPs on the GPU, one workgroup per QP: 256 threads and four
+// workgroups per CU for M + J <= 12 rows, 512 threads (two wavefronts per SIMD) and one workgroup per CU for more rows -- the
+// build whose inv(lu(B)), Y.c refresh and xb sum know that a simplex basis is mostly unit columns (see invert_lu, refreshY).
+// (The headline shapes go through the one-wavefront-per-QP kernel, ssqp_phase1_wave.h; this file takes every other shape.)
 //
 // Replaces initQP (reference: src/SSQP.jl:461-560) and the bounded-variable simplex it calls, cDantzigLP
 // (src/Simplex.jl:445-615), as the host C++ version in ssqp_host.cpp (phase1_one / BoundedSimplex) does -- and is
@@ -105,6 +108,45 @@ __device__ __forceinline__ int compact_columns(int tid, int n, int *list, int *c
     }
     __syncthreads();
     return *cnt;
+}
+
+// The same list by the whole workgroup (NT threads): every thread evaluates eight columns' flags at once -- ONE memory round trip
+// per 8 NT columns instead of one per 512 -- the wavefronts' ballot counts go through LDS (wcnt: 8 NT / 64 ints), every thread
+// forms its own bases from them, ascending k = (round, wavefront, lane).  Returns the count to every thread.
+template <int NT, class Pred>
+__device__ __forceinline__ int compact_columns_wg(int tid, int n, int *list, int *wcnt, Pred pred) {
+    constexpr int NW = NT / 64, QR = 8;
+    const int lane = tid & 63, wave = tid >> 6;
+    int total = 0;
+    for (int k0 = 0; k0 < n; k0 += QR * NT) {
+        bool f[QR];
+        unsigned long long m[QR];
+#pragma unroll
+        for (int q = 0; q < QR; ++q) {
+            const int k = k0 + q * NT + tid;
+            f[q] = (k < n) && pred(k);
+        }
+#pragma unroll
+        for (int q = 0; q < QR; ++q) {
+            m[q] = __ballot(f[q]);
+            if (lane == 0) wcnt[q * NW + wave] = __popcll(m[q]);
+        }
+        __syncthreads();
+        int run = total, mine[QR];
+#pragma unroll
+        for (int q = 0; q < QR; ++q)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                if (w == wave) mine[q] = run;
+                run += wcnt[q * NW + w];
+            }
+#pragma unroll
+        for (int q = 0; q < QR; ++q)
+            if (f[q]) list[mine[q] + __popcll(m[q] & ((1ull << lane) - 1ull))] = k0 + q * NT + tid;
+        total = run;
+        __syncthreads();
+    }
+    return total;
 }
 
 __device__ __forceinline__ void wave_order() {
@@ -252,7 +294,7 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
             }
         }
         if (!dense) break;   // (the last step is through; the barrier before the columns of the inverse orders the writes above)
-        __syncthreads();
+        if (nMv) __syncthreads();   // (rows were written: the exchange below reads them; the marks alone need no barrier)
         const int p = piv[k], info = stepInfo[k];
         // rows k and p change places in every column but k (thread j < 128 takes column j); column k: a(i, k) = a(i', k) / pivot
         // for i > k with i' the row the swap brings to i, and the pivot itself moves to (k, k) (thread 128 + i - k - 1)
@@ -1259,7 +1301,9 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
         __syncthreads();
         // xb = invB*b - Y*x[nonbasic]: the nonbasic columns at a nonzero value, ascending
         {
-            const int cnt = compact_columns(tid, N1, list, &misc[0], [&](int kk) { return nonbasic[kk] && x[kk] != 0.0; });
+            auto atBound = [&](int kk) { return nonbasic[kk] && x[kk] != 0.0; };
+            const int cnt = FEW ? compact_columns(tid, N1, list, &misc[0], atBound)
+                                : compact_columns_wg<NT1>(tid, N1, list, reinterpret_cast<int *>(terms), atBound);
             // the sum runs over the listed columns in ascending order, one rounded multiply and one rounded add per term
             // (the host's order): the PRODUCTS of a chunk of columns are formed by all threads at once (one memory round
             // trip for the chunk instead of one per term), the adds stay in order
@@ -1470,7 +1514,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
 }
 
 template <bool BIG>
-__global__ __launch_bounds__(NTB<BIG>, BIG ? 1 : 4) void ssqp_phase1_kernel(P1Params P) {  // (four workgroups per CU: 1,024 QPs resident)
+__global__ __launch_bounds__(NTB<BIG>, BIG ? 1 : 4) void ssqp_phase1_kernel(P1Params P) {  // (few rows: four workgroups per CU, 1,024 QPs resident)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // one QP per workgroup; on a list (what the wavefront kernel left) a bounded grid strides over it
     const int n = P.list ? (int)*P.listCount : P.nprob;
