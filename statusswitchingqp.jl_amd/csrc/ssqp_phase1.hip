@@ -37,7 +37,7 @@ constexpr double INF = __builtin_huge_val();
 
 // ---- diagnostic build only (-DSSQP_PHASE_PROFILE): cycles per phase of the kernel, thread 0 of every workgroup ----
 #ifdef SSQP_PHASE_PROFILE
-static __device__ unsigned long long g_p1phase[16];
+static __device__ unsigned long long g_p1phase[24];
 #define P1_DECL unsigned long long p1t = __builtin_amdgcn_s_memtime(); unsigned long long p1a[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define P1_STAMP(slot)                                                   \
     do {                                                                 \
@@ -188,6 +188,9 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
         wave_order();
     }
     for (int k = 0;;) {
+#ifdef SSQP_PHASE_PROFILE
+        const unsigned long long eT0 = __builtin_amdgcn_s_memtime();
+#endif
         if (tid < 64) {
             // Wavefront 0 walks the steps from k on.  A step whose L column is zero updates nothing: its whole effect is the
             // exchange of two rows.  During a run of such steps nothing in the matrix changes, so the exchange is only NOTED --
@@ -202,15 +205,19 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
             double c0 = r0 < n ? a[(size_t)kk * n + r0] : 0.0, c1 = r1 < n ? a[(size_t)kk * n + r1] : 0.0;
             for (;;) {
                 const bool v0 = r0 < n && lg0 >= kk, v1 = r1 < n && lg1 >= kk;
-                // the FIRST largest |a(i, kk)| over the logical rows i = kk .. n - 1 (the host's strict ">" scan)
-                const KeyMin cur = keymin(KeyMin{v0 ? -fabs(c0) : 1.0, v0 ? lg0 : 0x7fffffff}, KeyMin{v1 ? -fabs(c1) : 1.0, v1 ? lg1 : 0x7fffffff});
-                const KeyMin km = wave_keymin(cur);
-                ok = !(km.v == 0.0 || km.ord >= n);   // (-0.0: the whole column is zero; no order: nothing but NaN)
-                if (!ok) break;
-                const int p = km.ord;
-                const bool l0 = v0 && lg0 != p && c0 != 0.0, l1 = v1 && lg1 != p && c1 != 0.0;   // nonzeros of the L column
-                const unsigned long long m0 = __ballot(l0), m1 = __ballot(l1);
-                if ((m0 | m1) == 0ull) {
+                // (the next column, in case this step turns out to be an exchange only: nothing is written until then)
+                const int kn = kk + 1 < n ? kk + 1 : kk;
+                const double n0 = r0 < n ? a[(size_t)kn * n + r0] : 0.0, n1 = r1 < n ? a[(size_t)kn * n + r1] : 0.0;
+                // how many candidates are not exactly zero?  One: it is the pivot and the L column is zero -- the step of a unit
+                // column, most steps -- and no reduction is needed to find it.  None: the pivot is exactly 0.
+                const unsigned long long z0 = __ballot(v0 && c0 != 0.0), z1 = __ballot(v1 && c1 != 0.0);
+                const int nnz = __popcll(z0) + __popcll(z1);
+                if (nnz == 0) {
+                    ok = false;
+                    break;
+                }
+                if (nnz == 1) {
+                    const int p = z0 ? __builtin_amdgcn_readlane(lg0, __builtin_ctzll(z0)) : __builtin_amdgcn_readlane(lg1, __builtin_ctzll(z1));
                     if (p != kk) {
                         lg0 = lg0 == kk ? p : (lg0 == p ? kk : lg0);
                         lg1 = lg1 == kk ? p : (lg1 == p ? kk : lg1);
@@ -221,10 +228,18 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
                         stepInfo[kk] = 0;
                     }
                     if (++kk == n) break;
-                    c0 = r0 < n ? a[(size_t)kk * n + r0] : 0.0;
-                    c1 = r1 < n ? a[(size_t)kk * n + r1] : 0.0;
+                    c0 = n0;
+                    c1 = n1;
                     continue;
                 }
+                // the FIRST largest |a(i, kk)| over the logical rows i = kk .. n - 1 (the host's strict ">" scan)
+                const KeyMin cur = keymin(KeyMin{v0 ? -fabs(c0) : 1.0, v0 ? lg0 : 0x7fffffff}, KeyMin{v1 ? -fabs(c1) : 1.0, v1 ? lg1 : 0x7fffffff});
+                const KeyMin km = wave_keymin(cur);
+                ok = !(km.v == 0.0 || km.ord >= n);   // (no order: nothing but NaN)
+                if (!ok) break;
+                const int p = km.ord;
+                const bool l0 = v0 && lg0 != p && c0 != 0.0, l1 = v1 && lg1 != p && c1 != 0.0;   // nonzeros of the L column: at least one
+                const unsigned long long m0 = __ballot(l0), m1 = __ballot(l1);
                 // a step with a nonzero L column: its lists in LOGICAL rows (what is physical once the rows have been moved),
                 // at the positions after this step's own exchange of kk and p
                 dense = true;
@@ -272,6 +287,14 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
             }
         }
         __syncthreads();
+#ifdef SSQP_PHASE_PROFILE
+        const unsigned long long eT1 = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {
+            (void)__hip_atomic_fetch_add(&g_p1phase[17], eT1 - eT0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add(&g_p1phase[16], (unsigned long long)(ctrl[3] != 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add(&g_p1phase[19], (unsigned long long)(ctrl[2] != 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#endif
         if (!*flag) return false;
         const int k0 = k, nMv = ctrl[2];
         const bool dense = ctrl[3] != 0;
@@ -342,6 +365,9 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
             }
             __syncthreads();
         }
+#ifdef SSQP_PHASE_PROFILE
+        if (tid == 0) (void)__hip_atomic_fetch_add(&g_p1phase[18], __builtin_amdgcn_s_memtime() - eT1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         if (++k >= n) break;
     }
     __syncthreads();
@@ -1582,9 +1608,9 @@ hipError_t launch_phase1(int nprob, int N, int M, int J, const double *A, const 
 
 #ifdef SSQP_PHASE_PROFILE
 int phase1_debug_phases(unsigned long long *out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(p1::g_p1phase), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(p1::g_p1phase), 24 * sizeof(unsigned long long)) != hipSuccess) return 1;
     if (reset) {
-        static unsigned long long zero[16];
+        static unsigned long long zero[24];
         if (hipMemcpyToSymbol(HIP_SYMBOL(p1::g_p1phase), zero, sizeof(zero)) != hipSuccess) return 1;
     }
     return 0;

@@ -13,7 +13,7 @@ cfg = pkg.CONFIGS[name]
 db, prob, x0, S0 = pkg.DeviceBatch.generated(cfg, nprob)
 lib = pkg._capi.lib()
 lib.ssqp_debug_phase1_phases.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 24)()
 db.ctx.set_option("phase1_wave", 0)
 db.phase1(); db.torch.cuda.synchronize()
 lib.ssqp_debug_phase1_phases(out, 1)
@@ -30,6 +30,8 @@ for i, n in enumerate(names):
 if out[10] or out[11]:
     print("  inv(lu(B)) of the many-rows build: elimination %.0f, columns of the inverse %.0f cycles per basis change" % (
         out[10] / max(bc, 1), out[11] / max(bc, 1)))
+    print("  elimination per basis change: %.1f steps with a nonzero L column, %.1f runs with moved rows; wavefront 0 alone %.0f cycles, workgroup phases %.0f" % (
+        out[16] / max(bc, 1), out[19] / max(bc, 1), out[17] / max(bc, 1), out[18] / max(bc, 1)))
     print("  Y.c refresh of the many-rows build, column loop per refresh: group set-up + first loads %.0f, step blocks %.0f, row sums %.0f cycles" % (
         out[9] / max(bc + 1, 1), out[12] / max(bc + 1, 1), out[13] / max(bc + 1, 1)))
 
