@@ -239,6 +239,34 @@ __device__ __forceinline__ void row_dot2(const double *__restrict__ row, const d
     }
 }
 
+// The same for TWO rows at once, sixteen 16-byte loads per lane in flight (large N: with one workgroup on the chip a row at a
+// time, four loads deep, waits out an L2 round trip per KiB).  Per row the sums run in row_dot2's order: the same bits.
+__device__ __forceinline__ void rows2_dot2(const double *__restrict__ rowA, const double *__restrict__ rowB, const double *w1,
+                                           const double *w2, int N, int lane, double &a1A, double &a2A, double &a1B, double &a2B) {
+    a1A = a2A = a1B = a2B = 0.0;
+    for (int r0 = lane * 2; r0 < N; r0 += 128 * 8) {
+        double2 va[8], vb[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int r = r0 + 128 * m < N ? r0 + 128 * m : lane * 2;
+            va[m] = *reinterpret_cast<const double2 *>(rowA + r);
+            vb[m] = *reinterpret_cast<const double2 *>(rowB + r);
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int r = r0 + 128 * m;
+            if (r < N) {
+                const double2 x = *reinterpret_cast<const double2 *>(w1 + r);
+                const double2 y = *reinterpret_cast<const double2 *>(w2 + r);
+                a1A = fma(va[m].y, x.y, fma(va[m].x, x.x, a1A));
+                a2A = fma(va[m].y, y.y, fma(va[m].x, y.x, a2A));
+                a1B = fma(vb[m].y, x.y, fma(vb[m].x, x.x, a1B));
+                a2B = fma(vb[m].y, y.y, fma(vb[m].x, y.x, a2B));
+            }
+        }
+    }
+}
+
 // Partial dot products of four V columns with the LDS vector w: 16 independent
 // 16-byte loads per lane in flight at N = 512 (4 KiB per wave instruction group).
 template <int VEC>
@@ -2029,7 +2057,24 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
             const int r = L.rowsE[w];
             const double *__restrict__ row = Ct + (size_t)r * N;
             double acc = 0.0;
-            if (VEC >= 2) {
+            if (VEC >= 3) {  // (large N: eight 16-byte loads per lane in flight; the sum in the same order)
+                for (int i0 = lane * 2; i0 < N; i0 += 128 * 8) {
+                    double2 v8[8];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) v8[m] = *reinterpret_cast<const double2 *>(row + (i0 + 128 * m < N ? i0 + 128 * m : lane * 2));
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const int i = i0 + 128 * m;
+                        if (i < N) {
+                            const double2 zz = *reinterpret_cast<const double2 *>(L.zm + i);
+                            const int p0 = L.pos[i], p1 = L.pos[i + 1];
+                            acc = fma(v8[m].y, zz.y, fma(v8[m].x, zz.x, acc));
+                            if (p0 >= 0) X[w + W0 * p0] = v8[m].x;
+                            if (p1 >= 0) X[w + W0 * p1] = v8[m].y;
+                        }
+                    }
+                }
+            } else if (VEC >= 2) {
 #pragma unroll 4
                 for (int i = lane * 2; i < N; i += 128) {
                     const double2 v = *reinterpret_cast<const double2 *>(row + i);
@@ -2445,6 +2490,22 @@ __device__ __forceinline__ int iterate_kkt(ProbCtx &C, const Lds &L, double *ar,
                 }
             }
         } else {
+            if (VEC >= 3) {  // (large N: two rows per wavefront and round)
+                for (int o = wave; o < JO; o += 2 * NW) {
+                    const int o2 = o + NW < JO ? o + NW : o;
+                    const int j = L.iO[o], j2 = L.iO[o2];
+                    double az, ap, az2, ap2;
+                    rows2_dot2(Ct + (size_t)(M + j) * N, Ct + (size_t)(M + j2) * N, L.z, L.zm, N, lane, az, ap, az2, ap2);
+                    az = wave_sum(az);
+                    ap = wave_sum(ap);
+                    az2 = wave_sum(az2);
+                    ap2 = wave_sum(ap2);
+                    if (lane == 0) {
+                        L.lin[o] = (ap > tol) ? (rhs[M + j] - az) / ap : inf;
+                        if (o + NW < JO) L.lin[o + NW] = (ap2 > tol) ? (rhs[M + j2] - az2) / ap2 : inf;
+                    }
+                }
+            } else
             for (int o = wave; o < JO; o += NW) {
                 const int j = L.iO[o];
                 const double *__restrict__ row = Ct + (size_t)(M + j) * N;
