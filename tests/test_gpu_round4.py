@@ -190,3 +190,37 @@ def test_phase1_many_rows_build(pkg, orc, shape, kind):
     assert np.array_equal(db.S0.cpu().numpy(), Sh) and np.array_equal(db.x0.cpu().numpy(), xh), (shape, kind)
     if kind == "infeasible":
         assert (sth == 0).all()
+
+
+def test_phase1_many_rows_random_shapes(pkg):
+    """forty random shapes with 13 .. 88 rows (N 16 .. 160, equality rows 1 .. 6, the rest inequalities; bounds tight, loose, partly
+    free, partly infeasible): the sparsity-aware elimination meets runs of exchanges before and after steps with a nonzero L
+    column, moved rows on both sides of lane 64, bases with few and with many dense columns -- (x0, S0, status) bit for bit the
+    host stage's on every problem"""
+    rng = np.random.default_rng(20261005)
+    seen = set()
+    for trial in range(40):
+        M0 = int(rng.integers(13, 89))
+        M = int(rng.integers(1, 7))
+        J = M0 - M
+        N = int(rng.integers(16, 161))
+        kind = ["tight", "loose", "free", "infeasible"][trial % 4]
+        ub = {"tight": 2.5 / N, "loose": 20.0 / N, "free": 0.0, "infeasible": 3.0 / N}[kind]
+        cfg = pkg.GenConfig(N, M, J, 2 * N, 1e-3, ub, float(rng.uniform(0.8, 1.3)), 0.2)
+        prob = pkg.generate_batch(cfg, 4, int(rng.integers(1, 2 ** 31)))
+        if kind == "free":
+            free = rng.random(N) < 0.2
+            prob["d"][:, free] = -np.inf
+            prob["u"][:, free] = np.inf
+            prob["u"][:, ~free] = 6.0 / N
+        if kind == "infeasible":
+            prob["u"][2:] = 0.5 / N
+        xh, Sh, sth = pkg.phase1_batch(prob)
+        db = pkg.DeviceBatch(prob, np.zeros((4, N + J), dtype=np.int32), np.zeros((4, N)))
+        st = db.phase1()
+        db.torch.cuda.synchronize()
+        assert np.array_equal(st.cpu().numpy(), sth), (trial, N, M, J, kind, st.cpu().numpy(), sth)
+        assert np.array_equal(db.S0.cpu().numpy(), Sh), (trial, N, M, J, kind)
+        assert np.array_equal(db.x0.cpu().numpy(), xh), (trial, N, M, J, kind)
+        seen.update(sth.tolist())
+    assert {0, 1} <= seen
