@@ -275,7 +275,7 @@ int ssqp_phase1_batch_f64(int nprob, int N, int M, int J, const double *A, const
  * QPs with free variables; option "phase1_wave"), asynchronous on
  * `stream`, bit-identical to the host version (same decisions, same summation orders, no FMA contraction), so the loop
  * that follows runs the same passes.  All pointers are device pointers; needs M + J small enough for the basis
- * inverse to fit in LDS (M + J <= 89; SSQP_ERR_UNSUPPORTED otherwise: use the host version).  dstatus as above.
+ * inverse to fit in LDS (M + J <= 87; SSQP_ERR_UNSUPPORTED otherwise: use the host version).  dstatus as above.
  * Above 12 rows the kernel (512 threads per QP) leaves out products with an exactly zero entry of inv(B) or of the LU
  * factors -- a simplex basis is mostly unit columns --, which changes no bit for FINITE data; an Inf or NaN in A / G, which
  * the host stage carries through such products (0 * Inf = NaN), may then give a different vertex or status. */

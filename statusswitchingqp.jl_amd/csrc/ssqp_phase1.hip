@@ -33,6 +33,7 @@ constexpr int NT1 = 256;   // threads per workgroup, few rows
 template <bool BIG> constexpr int NTB = BIG ? 512 : NT1;   // many rows: two wavefronts per SIMD (what bounds that build is
                                                             // instruction issue: a lone wavefront issues once in ~4.5 cycles)
 constexpr int XB_CHUNK = 32;   // columns of the xb sum whose products are formed together (staged in LDS)
+constexpr int XB_CHUNK_BIG = 40;   // ... in the many-rows build: cfg5 lists 25-40 columns, one chunk instead of two
 constexpr double INF = __builtin_huge_val();
 
 // ---- diagnostic build only (-DSSQP_PHASE_PROFILE): cycles per phase of the kernel, thread 0 of every workgroup ----
@@ -663,7 +664,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
     double *blo = acc + M0, *bhi = blo + M0;       // bounds of the basic variables by row
     double *redv = bhi + M0;                       // 4 (many rows: 12 -- one per wavefront for the block maximum, [8]: the leaving bound)
     double *terms = redv + (BIG ? 12 : 4);                      // XB_CHUNK x M0: products Y[r, k] x[k] of the xb sum, a chunk of columns at a time
-    int *basis = reinterpret_cast<int *>(terms + (size_t)XB_CHUNK * M0);  // M0
+    int *basis = reinterpret_cast<int *>(terms + (size_t)(BIG ? XB_CHUNK_BIG : XB_CHUNK) * M0);  // M0
     int *piv = basis + M0;                         // 2 M0 (row swaps of the LU, then the positions of the permuted unit vectors)
     int *redi = piv + 2 * M0;                      // 4 (many rows: 8)
     int *misc = redi + (BIG ? 8 : 4);                          // [0] count, [1] flag, [2] action, [3] leaveStatus, [4] n free, [5] n upperOnly
@@ -1087,6 +1088,10 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
         if (bidx == 0x7fffffff) break;  // no improving candidate: optimal
         const int k = bidx;
         const double *ak = A1 + k;  // (entry t of column k: ak[t * N1])
+        if (!FEW) {  // (many rows: the column goes to LDS in one round trip -- the LU's scratch is idle -- instead of eight entries per trip)
+            for (int t = tid; t < M0; t += NT1) Bm[t] = ak[(size_t)t * N1];
+            __syncthreads();
+        }
         for (int r = tid; r < M0; r += NT1) {
             double s = 0.0;
             if (FEW) {  // (the column's entries and the row of invB are requested together: one round trip)
@@ -1107,7 +1112,7 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                     for (int q = 0; q < 8; ++q) {
                         const int t = t0 + q < M0 ? t0 + q : t0;
                         iv8[q] = invB[(size_t)t * M0 + r];
-                        av8[q] = ak[(size_t)t * N1];
+                        av8[q] = Bm[t];
                     }
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
@@ -1340,9 +1345,9 @@ __device__ __forceinline__ void phase1_one_wg(const P1Params &P, const int prob,
                 // cycles per pass on cfg5 -- and thread (g, r) forms row r of the columns g, g + G, ... of the chunk: one entry
                 // of inv(B) is read per step for up to XBC columns, the LP's entries are broadcast reads.  Per element the
                 // sum runs over t ascending, as refreshY forms Y[r, k].
-                constexpr int XBC = 8;                                             // (XB_CHUNK = 32 columns = 4 groups x 8)
+                constexpr int XBC = XB_CHUNK_BIG / 4;                              // (XB_CHUNK_BIG = 40 columns = 4 groups x 10)
                 const int G = 4;                                                   // column groups: 4 M0 <= 512 threads (M0 <= 128)
-                const int chunk = XB_CHUNK < M0 ? XB_CHUNK : M0;                   // (chunk x M0 doubles fit the scratch)
+                const int chunk = XB_CHUNK_BIG < M0 ? XB_CHUNK_BIG : M0;           // (chunk x M0 doubles fit the scratch)
                 const int g = tid / M0, r = tid - g * M0;
                 double *Ac = Bm;                                                   // column t of the chunk at t * M0
                 for (int t0 = 0; t0 < cnt; t0 += chunk) {
@@ -1562,7 +1567,8 @@ size_t phase1_ws_ints(int N, int M, int J) {
 }
 size_t phase1_lds_bytes(int M, int J) {  // without the N1-vectors
     const size_t M0 = (size_t)(M + J);
-    return (2 * M0 * M0 + (M0 > 12 ? 15 : 8) * M0 + (M0 > 12 ? 12 : 4) + p1::XB_CHUNK * M0) * 8 + (3 * M0 + (M0 > 12 ? 8 : 4) + 8) * 4 + 64;
+    return (2 * M0 * M0 + (M0 > 12 ? 15 : 8) * M0 + (M0 > 12 ? 12 : 4) + (M0 > 12 ? p1::XB_CHUNK_BIG : p1::XB_CHUNK) * M0) * 8 +
+           (3 * M0 + (M0 > 12 ? 8 : 4) + 8) * 4 + 64;
 }
 // with x, colnorm, sdot, S1, nonbasic of up to N1x = 2N + J + M0 columns in LDS
 static size_t phase1_lds_bytes_vec(int N, int M, int J) {
