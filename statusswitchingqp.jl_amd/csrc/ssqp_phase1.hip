@@ -165,22 +165,24 @@ __device__ __forceinline__ void wave_order() {
 // only ever subtracted from (a difference is never -0.0 unless its first operand was), and a zero of either sign gives the
 // same pivot search (|.|), the same products (+-0.0, added to sums that are never -0.0) and the same "pivot is exactly 0"
 // verdict.  Likewise a column entry of the inverse that is 0 before its division stays +0.0 where the host has 0 / U = +-0.0.
-//   * elimination step k: wavefront 0 finds the pivot (first maximum: value, then smallest row among the ties), lists the
-//     nonzero rows of the L column and the nonzero columns of the U row by ballot, and publishes 1 / pivot; after ONE barrier
-//     the rows k and p change places in every column and column k is scaled (distinct threads, distinct elements); the
-//     trailing update -- a second barrier, and a third behind it -- runs over (listed rows) x (listed columns) and not at
-//     all when the L column is zero, the common case;
-//   * columns of the inverse: three lanes of one wavefront per column, 21 columns per wavefront, no barrier between steps; a
+//   * elimination step k: wavefront 0 looks at column k.  ONE candidate that is not exactly zero: a unit column -- that entry
+//     is the pivot, the L column is zero, the step is an exchange of two rows and nothing else; a run of such steps is walked
+//     by wavefront 0 alone with the rows' logical positions in registers (see the loop).  More: the pivot by a wavefront
+//     reduction (first maximum: value, then smallest row among the ties), the nonzero rows of the L column listed by ballot;
+//     after ONE barrier the rows k and p change places in every column and column k is scaled (distinct threads, distinct
+//     elements, 1 / pivot by every scaling thread); after a second the trailing update runs over (listed rows) x (columns with
+//     a nonzero entry in the U row), and a third barrier ends the step;
+//   * columns of the inverse: three (six) lanes of one wavefront per column, no barrier between steps; a
 //     forward step whose L column is zero is not walked at all (a bit mask in scalar registers), neither is a step at which
-//     none of the wavefront's columns has a nonzero entry, and a backward step whose U column is empty is the division only.
+//     none of the wavefront's columns has a nonzero entry; the backward pass walks only the steps with a nonempty U column, the
+//     divisions of the other entries wait until the end (nobody reads them before).
 template <int NT>
 __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double *vec, int *piv, int n, int *flag) {
     const int lane = tid & 63;
     // (vec: 4 n doubles = 8 n ints)
-    int *Lnz = reinterpret_cast<int *>(vec), *Unz = Lnz + n, *hasU = Lnz + 2 * n, *physOf = Lnz + 3 * n, *mv = Lnz + 4 * n;
+    int *Lnz = reinterpret_cast<int *>(vec), *hasU = Lnz + 2 * n, *physOf = Lnz + 3 * n, *mv = Lnz + 4 * n;
     int *ctrl = Lnz + 5 * n;   // [0] the step the workgroup takes up (n: none is left), [1] where the run started, [2] rows to move
-    double *rinvp = reinterpret_cast<double *>(Lnz + ((5 * n + 8 + 1) & ~1));   // 1 / pivot of the step taken up
-    int *stepInfo = piv + n;                                                     // nL | nU << 8 of step k
+    int *stepInfo = piv + n;                                                     // nL of step k (0: an exchange only)
 #ifdef SSQP_PHASE_PROFILE
     const unsigned long long luT0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -248,23 +250,11 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
                 if (l0) Lnz[__popcll(m0 & below)] = lg0 == kk ? p : lg0;
                 if (l1) Lnz[__popcll(m0) + __popcll(m1 & below)] = lg1 == kk ? p : lg1;
                 const int nL = __popcll(m0) + __popcll(m1);
-                const unsigned long long h0 = __ballot(r0 < n && lg0 == p);
-                const int pPhys = h0 ? __builtin_ctzll(h0) : 64 + __builtin_ctzll(__ballot(r1 < n && lg1 == p));
-                int nU = 0;
-                for (int jb = kk + 1; jb < n; jb += 64) {  // columns of the U row (the pivot's row) that are not exactly zero
-                    const int j = jb + lane;
-                    const bool f = j < n && a[(size_t)j * n + pPhys] != 0.0;
-                    const unsigned long long m = __ballot(f);
-                    if (f) {
-                        Unz[nU + __popcll(m & below)] = j;
-                        hasU[j] = 1;
-                    }
-                    nU += __popcll(m);
-                }
+                // (the U row's nonzero columns are found by the update itself and 1 / pivot by the threads that scale the column:
+                //  both would be a dependent LDS round trip and a division in THIS wavefront's chain, which every step waits for)
                 if (lane == 0) {
                     piv[kk] = p;
-                    stepInfo[kk] = nL | (nU << 8);
-                    *rinvp = 1.0 / a[(size_t)kk * n + pPhys];
+                    stepInfo[kk] = nL;
                 }
                 break;
             }
@@ -333,22 +323,25 @@ __device__ __forceinline__ bool invert_lu(int tid, double *a, double *x, double 
             const int i = k + 1 + (tid - 128);
             if (i < n) {
                 double *colk = a + (size_t)k * n;
-                const double r = *rinvp;
                 const double src = colk[i == p ? k : i], pv = colk[p];
+                const double r = 1.0 / pv;       // (every thread: cheaper than one division in wavefront 0's chain and a broadcast)
                 colk[i] = src * r;               // a(i, k) *= 1 / a(k, k)
                 if (i == p) colk[k] = pv;
             }
         }
         __syncthreads();
-        const int nL = info & 255, nU = info >> 8;
-        if (nU > 0) {
-            // a(i, j) -= a(i, k) * a(k, j) over the listed rows and columns: thread (cj = tid >> 4, ri = tid & 15) takes the
-            // listed rows ri + 16 m of the listed columns cj + 16 g, five rows per LDS round trip
+        const int nL = info & 255;
+        {
+            // a(i, j) -= a(i, k) * a(k, j) over the listed rows and the columns with a nonzero entry in the U row: thread
+            // (cj = tid >> 4, ri = tid & 15) takes the listed rows ri + 16 m of the columns k + 1 + cj + (NT / 16) g, five rows per
+            // LDS round trip; a column with an entry in the U row has a nonempty U column
             const int cj = tid >> 4, ri = tid & 15;
             const double *colk = a + (size_t)k * n;
-            for (int jj = cj; jj < nU; jj += NT / 16) {
-                double *colj = a + (size_t)Unz[jj] * n;
+            for (int j = k + 1 + cj; j < n; j += NT / 16) {
+                double *colj = a + (size_t)j * n;
                 const double uj = colj[k];
+                if (uj == 0.0) continue;
+                if (ri == 0) hasU[j] = 1;
                 for (int i0 = ri; i0 < nL; i0 += 16 * 5) {
                     int ix[5];
                     double ov[5], lv[5];
