@@ -224,3 +224,19 @@ def test_phase1_many_rows_random_shapes(pkg):
         assert np.array_equal(db.x0.cpu().numpy(), xh), (trial, N, M, J, kind)
         seen.update(sth.tolist())
     assert {0, 1} <= seen
+
+
+def test_phase1_many_rows_wide_lp(pkg):
+    """N1 = N + J + M + J > 8 x 512 columns: the workgroup-wide list of the columns at a nonzero bound takes a second round
+    (csrc/ssqp_phase1.hip, compact_columns_wg), the Y.c refresh more than two column blocks -- bit-identical to the host stage"""
+    N, M, J = 4400, 2, 14
+    cfg = pkg.GenConfig(N, M, J, 64, 1e-3, 30.0 / N, 1.0, 0.2)
+    prob = pkg.generate_batch(cfg, 2, 31337)
+    xh, Sh, sth = pkg.phase1_batch(prob)
+    assert (sth == 1).all()
+    db = pkg.DeviceBatch(prob, np.zeros((2, N + J), dtype=np.int32), np.zeros((2, N)))
+    st = db.phase1()
+    db.torch.cuda.synchronize()
+    assert np.array_equal(st.cpu().numpy(), sth)
+    assert np.array_equal(db.S0.cpu().numpy(), Sh) and np.array_equal(db.x0.cpu().numpy(), xh)
+    assert (xh != 0).sum(axis=1).min() >= 30          # (the list of columns at a nonzero bound is not trivial)
