@@ -69,6 +69,10 @@ def parse_args():
                          "the median (SURVEY.md 8d: median of >= 5 repetitions)")
     ap.add_argument("--keep-stats", action="store_true",
                     help="time the accounting builds (statistics pointer passed) instead of the lean ones: A/B runs")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="a context option of the library (include/ssqp_hip.h: wave_kernel, wave_qp_per_cu, ...) set on every "
+                         "lane on top of the mode's own; recorded in config.options, and the PMC file (collected with the "
+                         "defaults) is then not quoted")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_counters.json"),
                     help="per-launch PMC figures (HBM bytes, SQ counters) from separate rocprofv3 --pmc passes")
     return ap.parse_args()
@@ -179,6 +183,9 @@ def run(args):
             ln.ctx.sync(ln.stream.cuda_stream)
             for k, v in MODES[mode].items():
                 ln.ctx.set_option(k, v)
+            for kv in args.option:                      # (the caller's own choices win over the mode's)
+                k, v = kv.split("=", 1)
+                ln.ctx.set_option(k, int(v))
         torch.cuda.synchronize(dev)
 
     def lane_stream(i):
@@ -439,7 +446,7 @@ def run(args):
 
     # PMC figures are quoted only when they were collected on exactly this kernel source and workload
     pmc = None
-    if os.path.exists(args.pmc_json):
+    if os.path.exists(args.pmc_json) and not args.option:
         try:
             with open(args.pmc_json) as f:
                 pj = json.load(f)
@@ -530,7 +537,7 @@ def run(args):
                                    "resident in HBM; %d distinct batches per GPU (seeds %d + lane*%d), one per launch lane"
                                    % (args.config, P, N, batch.M, J, cfg.delta, cfg.ub, nlanes, lanes[0].seed0, P),
                        "qps_per_gpu": P,
-                       "compute_units": num_cu,
+                       "compute_units": num_cu, "options": dict(kv.split("=", 1) for kv in args.option),
                        "parallelism": "one QP per wavefront (%d per CU in the timed region), batch sharded over %d GPU(s)"
                                       % (qpc_timed, world),
                        "formulation": "dense (reference-shaped)" if args.dense else "default (kept factor, cached products)"},

@@ -5,6 +5,8 @@ run() { name=$1; shift; timeout -k 10 500 python bench.py "$@" > gpurun_out/conf
 run cfg1 --config cfg1 --nprob 1024 --steps 10 --warmup 2 --cpu-seconds 4
 run cfg2 --config cfg2 --nprob 1 --steps 10 --warmup 2 --cpu-seconds 3
 run cfg3 --config cfg3 --nprob 1024 --steps 6 --warmup 2 --cpu-seconds 6 --pmc-json profiles/pmc_counters_cfg3.json
+# (the same with the caller's option for workloads known to end with large free sets: the big-factor build from the first pass)
+run cfg3_wave_kernel2 --config cfg3 --nprob 1024 --steps 6 --warmup 2 --no-cpu --skip-dense --option wave_kernel=2
 run cfg4 --config cfg4 --nprob 1024 --steps 20 --warmup 3 --cpu-seconds 8
 run cfg4_serial --config cfg4 --nprob 1024 --steps 6 --warmup 1 --streams 1 --no-cpu --skip-dense
 run cfg5 --config cfg5 --nprob 1 --steps 3 --warmup 1 --cpu-seconds 3
