@@ -416,11 +416,12 @@ def test_cfg3_full_batch_1024(pkg, orc):
         assert (((stats["path"] & 64) != 0).all()) == (not opts or "wave_kernel" not in opts)
 
 
-@pytest.mark.parametrize("N", [768, 601])
+@pytest.mark.parametrize("N", [768, 601, 1500])
 def test_wide_n_kernels(pkg, orc, N):
-    """N in 513..1024 even (ssqp_solve_kernel<3,1>: eight accumulator slots per lane) and odd N > 512 (scalar loads
-    with the maximum number of per-thread slots)"""
-    cfg = pkg.GenConfig(N, 1, 3, 2 * N, 1e-3, 4.0 / N, 1.05, 0.1)
+    """N in 513..1024 even (ssqp_solve_kernel<3,1>: eight accumulator slots per lane), odd N > 512 (scalar loads
+    with the maximum number of per-thread slots) and N = 1500 with fourteen inequality rows (ssqp_solve_kernel<4,1>; the
+    eight-loads-deep row streams of the ratio test and the E-row sweep end in a partial second batch)"""
+    cfg = pkg.GenConfig(N, 1, 3 if N < 1100 else 14, 2 * N if N < 1100 else N, 1e-3, 4.0 / N, 1.05, 0.1)
     run_cfg(pkg, orc, cfg, 2, seed0=1234 + N)
 
 
